@@ -1,0 +1,136 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference, which never travels to
+the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports emakryo/gaussian_process unmodified from /root/reference, runs it on
+seeded inputs and stores inputs + outputs as small .npz files (data only).  The
+committed .npz files pin ``oracle/gp_oracle.py`` (tests/test_oracle_golden.py)
+and, through it and directly, the HIP path (tests/test_gpu_*.py).
+
+Cases:
+  g1_rbf1d_n15     examples/regression_1d.ipynb cells 2-3 (n=15), fixed theta
+  g1_rbf1d_n200    same generator at n=200 (BASELINE config 1 wording)
+  g2_ard2d         examples/ARD_regression_2d.ipynb cells 2-5 (n_train=100) incl. empirical Bayes
+  g3_ard8_n{256,1024,4096}   synthetic ARD d=8 workload of SURVEY 8(d), m=256
+  g4_ep_moons_n{50,200}      examples/expectation_propagation.ipynb split; _ep(K, shuffle=False)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+from gaussian_process import GaussianProcessRegression, GaussianProcessExpectationPropagation  # noqa: E402
+from gaussian_process.kernels import RBF, ARD  # noqa: E402
+from gaussian_process.datasets import generate_gp  # noqa: E402
+from oracle.gp_oracle import synthetic_ard  # noqa: E402  (input generator only)
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in kw.items()})
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def regression_case(name, gp, X, y, Xs, store_K=True, extra=None):
+    gp.fit(X, y)
+    cov = gp.cov
+    kv = cov(X)
+    n = X.shape[0]
+    lml = gp.log_marginal_likelihood()
+    grads = gp.grad_log_marginal_likelihood()
+    mean, pcov = gp.predict_with_variance(Xs)
+    import scipy.linalg as sla
+    Ky = kv.K + gp.sigma * np.eye(n)
+    L = sla.cholesky(Ky, lower=True)
+    a = sla.solve_triangular(L, y, lower=True)
+    alpha = sla.solve(Ky, y, assume_a="pos")
+    out = dict(X=X, y=y, Xs=Xs, kind=("ard" if isinstance(cov, ARD) else "rbf"),
+               cov_sigma=float(cov.sigma), cov_beta=np.atleast_1d(np.asarray(cov.beta, dtype=float)),
+               noise=float(gp.sigma), lml=lml, grad_sigma=grads["sigma"],
+               grad_cov_sigma=grads["cov__sigma"], grad_cov_beta=grads["cov__beta"],
+               mean=mean, diagL=np.diagonal(L).copy(), a=a, alpha=alpha)
+    if store_K:
+        out.update(K=kv.K, dsigma=kv.dtheta["sigma"], dbeta=kv.dtheta["beta"],
+                   Ks=cov(X, Xs).K, pcov=pcov)
+    else:
+        idx = np.random.default_rng(7).integers(0, n, size=(512, 2))
+        out.update(K_idx=idx, K_samples=kv.K[idx[:, 0], idx[:, 1]], K_sum=kv.K.sum(),
+                   pcov=pcov)
+    if extra:
+        out.update(extra)
+    save(name, **out)
+
+
+def main():
+    warnings.simplefilter("ignore")
+    # ---- G1: regression_1d notebook ------------------------------------
+    for n in (15, 200):
+        X, y = generate_gp(n_samples=n, kernel=RBF(beta=1.), random_state=1, noise=0.1)
+        Xs = np.linspace(-3, 3).reshape(-1, 1)
+        gp = GaussianProcessRegression(cov=RBF(), sigma=0.1)
+        extra = {}
+        if n == 15:
+            g2 = GaussianProcessRegression(cov=RBF(), sigma=0.1)
+            g2.fit(X, y)
+            g2.empirical_bayes()
+            extra = dict(eb_beta=g2.cov.beta, eb_cov_sigma=g2.cov.sigma, eb_noise=g2.sigma,
+                         eb_lml=g2.log_marginal_likelihood())
+        regression_case("g1_rbf1d_n%d" % n, gp, X, y, Xs, extra=extra)
+
+    # ---- G2: ARD_regression_2d notebook --------------------------------
+    from sklearn.model_selection import train_test_split
+    X, y = generate_gp(n_samples=200, n_features=2, kernel=ARD(beta=[1, 3]), random_state=0, noise=0.01)
+    Xtr, Xte, ytr, yte = train_test_split(X, y, train_size=0.5, random_state=0)
+    gp = GaussianProcessRegression(cov=ARD(beta=[1, 1]))
+    gp.fit(Xtr, ytr)
+    rmse0 = np.sqrt(np.mean((gp.predict(Xte) - yte) ** 2))
+    g2 = GaussianProcessRegression(cov=ARD(beta=[1, 1]))
+    g2.fit(Xtr, ytr)
+    g2.empirical_bayes()
+    rmse1 = np.sqrt(np.mean((g2.predict(Xte) - yte) ** 2))
+    regression_case("g2_ard2d", GaussianProcessRegression(cov=ARD(beta=[1, 1])), Xtr, ytr, Xte,
+                    extra=dict(yte=yte, rmse_before=rmse0, rmse_after=rmse1,
+                               eb_beta=g2.cov.beta, eb_cov_sigma=g2.cov.sigma, eb_noise=g2.sigma,
+                               eb_lml=g2.log_marginal_likelihood()))
+
+    # ---- G3: synthetic ARD d=8 ------------------------------------------
+    for n in (256, 1024, 4096):
+        X, y, Xs, beta = synthetic_ard(n, m=256, d=8, seed=0, noise=0.1)
+        gp = GaussianProcessRegression(cov=ARD(sigma=1.0, beta=beta), sigma=0.1)
+        regression_case("g3_ard8_n%d" % n, gp, X, y, Xs, store_K=(n == 256),
+                        extra=dict(seed=0, m=256))
+
+    # ---- G4: EP on make_moons -------------------------------------------
+    from sklearn.datasets import make_moons
+    for ntot in (100, 400):
+        X, y = make_moons(ntot, noise=0.1, random_state=0)
+        y = 2 * y - 1
+        Xtr, Xte, ytr, yte = train_test_split(X, y, train_size=0.5, random_state=0)
+        ep = GaussianProcessExpectationPropagation(RBF())
+        ep.Xtr, ep.ytr = Xtr, ytr
+        ep.n, ep.dim = Xtr.shape
+        K = ep.cov(Xtr).K
+        ep._ep(K, shuffle=False)
+        lml = ep.log_marginal_likelihood()
+        pm, pv = ep.posterior(Xte)
+        dec = ep.decision_function(Xte)
+        grads = ep.grad_log_marginal_likelihood()
+        save("g4_ep_moons_n%d" % (ntot // 2), Xtr=Xtr, ytr=ytr, Xte=Xte, yte=yte, K=K,
+             tau=ep.tau_tilde, nu=ep.nu_tilde, mu=ep.mu, diagSigma=np.diag(ep.Sigma),
+             Sigma=ep.Sigma if ntot == 100 else np.zeros(0),
+             diagL=np.diag(ep.L), z=ep.z, lml=lml, post_mean=pm, post_var=pv, decision=dec,
+             score=np.mean(np.sign(dec - 0.5) == yte),
+             grad_cov_sigma=grads["cov__sigma"], grad_cov_beta=grads["cov__beta"])
+
+
+if __name__ == "__main__":
+    main()
