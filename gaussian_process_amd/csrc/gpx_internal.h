@@ -1,0 +1,92 @@
+// Internal declarations shared by the libgpx translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "gpx.h"
+
+struct gpx_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // small library-owned scratch (partials of fixed-order reductions, info word)
+  double* red = nullptr;      // device, RED_ELEMS doubles
+  int* info_dev = nullptr;    // device int
+  double* host_pin = nullptr; // pinned host staging for scalars, HOST_PIN doubles
+};
+
+constexpr size_t GPX_RED_ELEMS = 1u << 23;  // 64 MiB of reduction partials
+constexpr size_t GPX_HOST_PIN = 4096;
+constexpr int GPX_MAXD = 32;  // max input dimension held in kernel-argument betas
+
+void gpx_set_error(const char* fmt, ...);
+
+#define GPX_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      gpx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GPX_EHIP;                                                                        \
+    }                                                                                         \
+  } while (0)
+
+#define GPX_REQUIRE(cond, ...)     \
+  do {                             \
+    if (!(cond)) {                 \
+      gpx_set_error(__VA_ARGS__);  \
+      return GPX_EINVAL;           \
+    }                              \
+  } while (0)
+
+static inline bool gpx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- operand layouts of the MFMA GEMM (gemm_f64.hip) -------------------------------------
+// op(A) is M x K.  KC: stored [M][K] (k contiguous).  RC: stored [K][M] (rows of op contiguous).
+// op(B) is K x N.  KC: stored [N][K] (k contiguous).  RC: stored [K][N].
+enum { GPX_LAY_KC = 0, GPX_LAY_RC = 1 };
+
+struct GemmDesc {
+  const double* A; long lda; int a_lay; int a_tri;  // a_tri: stored matrix is lower (row >= col valid)
+  const double* B; long ldb; int b_lay; int b_tri;
+  const double* Cin; long ldcin;  // may be null when beta == 0
+  double* D; long ldd;
+  int M, N, K;
+  double alpha, beta;
+  int c_lower;       // write only row >= col (D starts on the diagonal)
+  double diag_add;   // added to D[i][i]
+};
+
+int gpx_gemm_launch(hipStream_t s, const GemmDesc& g);
+
+// leaf kernels (leaf.hip)
+int gpx_leaf_potf2_inv(hipStream_t s, int nb, double* A, long lda, double* dinv_blk, int* info_dev,
+                       int global_off);
+int gpx_leaf_diag_inv_batched(hipStream_t s, int n, const double* L, long ldl, double* dinv);
+int gpx_copy_dinv_to_diag(hipStream_t s, int nb, const double* dinv_blk, double* L, long ldl);
+
+// gram.hip
+struct BetaArg { double b[GPX_MAXD]; };
+int gpx_gram_launch(hipStream_t s, const double* X1, int n1, long ldx1, const double* X2, int n2,
+                    long ldx2, int d, double sigma, const BetaArg& hb, double diag_add, double* K,
+                    long ldk, int uplo);
+int gpx_gram_dtheta_launch(hipStream_t s, const double* X1, int n1, long ldx1, const double* X2,
+                           int n2, long ldx2, int d, int nbeta, double sigma, const BetaArg& hb,
+                           double* K, double* dsigma, double* dbeta, long ld, size_t plane);
+int gpx_grad_trace_launch(hipStream_t s, const double* X, int n, long ldx, int d, int nbeta,
+                          double sigma, const BetaArg& hb, const double* alpha, const double* Kinv,
+                          long ldk, double* red, size_t red_elems, double* out_dev);
+
+// blas2.hip
+int gpx_logdet_launch(hipStream_t s, int n, const double* L, long ldl, double* red, double* out_dev);
+int gpx_dot_launch(hipStream_t s, int n, const double* x, const double* y, double* red, double* out_dev);
+int gpx_gemv_launch(hipStream_t s, int trans, int n, int m, const double* A, long lda,
+                    const double* x, double* y, double* red, size_t red_elems);
+int gpx_symmetrize_launch(hipStream_t s, int n, double* A, long lda);
+int gpx_diag_launch(hipStream_t s, int n, const double* A, long lda, double* out);
+int gpx_ep_scale_launch(hipStream_t s, int n, const double* K, long ldk, const double* sv, double* B,
+                        long ldb, double* SK, long ldsk);
+int gpx_sqrt_launch(hipStream_t s, int n, const double* x, double* y);
+int gpx_colsumsq_sub_launch(hipStream_t s, int n, int m, const double* V, long ldv, double base,
+                            double* var, double* red, size_t red_elems);

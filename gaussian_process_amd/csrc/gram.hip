@@ -1,0 +1,315 @@
+// Gram-matrix construction and the fused LML-gradient trace (HBM-bound kernels).
+//
+//   K[i][j] = sigma * exp(-0.5 * sum_k beta_k (x_ik - x'_jk)^2)      kernels.py:37 / 77-79
+//
+// RBF is the ARD formula with every beta_k equal (the reference evaluates RBF through the
+// |x|^2+|y|^2-2xy expansion, kernels.py:34-36; exact differences agree with it to ~2e-15 and
+// keep the diagonal exactly sigma).  The (n1,n2,d) tensors of kernels.py:77-80 never exist:
+// each output element is produced from LDS/register-resident rows of X and written once.
+//
+// Layout: a workgroup of 256 threads owns a 64-row x 128-column tile; each wave owns 16 rows
+// and every lane two adjacent columns, so one store instruction writes 1 KiB of one row
+// (16 B per lane, fully coalesced).  The two X2 rows of a lane live in registers (pre-scaled by
+// sqrt(beta_k)); the X1 rows are read from LDS at wave-uniform addresses (broadcast).
+#include <type_traits>
+
+#include "gpx_internal.h"
+
+namespace {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int GT_ROWS = 64, GT_COLS = 128, GT_THREADS = 256;
+
+struct GramArgs {
+  const double* X1; long ldx1; int n1;
+  const double* X2; long ldx2; int n2;
+  int d;
+  double sigma, diag_add;
+  double* K; long ldk;
+  int lower;
+  BetaArg sb;  // sqrt(beta_k)
+};
+
+// D > 0: compile-time dimension (unrolled, registers); D == 0: runtime d <= GPX_MAXD.
+template <int D>
+__global__ __launch_bounds__(GT_THREADS) void gram_kernel(const GramArgs a) {
+  __shared__ double sx1[GT_ROWS * GPX_MAXD];
+  const int d = D > 0 ? D : a.d;
+  const int r0 = blockIdx.y * GT_ROWS, c0 = blockIdx.x * GT_COLS;
+  if (a.lower && c0 > r0 + GT_ROWS - 1) return;  // tile strictly above the diagonal
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+
+  for (int e = t; e < GT_ROWS * d; e += GT_THREADS) {
+    const int r = e / d, k = e - r * d;
+    const int gr = r0 + r;
+    sx1[r * d + k] = gr < a.n1 ? a.X1[(long)gr * a.ldx1 + k] * a.sb.b[k] : 0.0;
+  }
+  const int c = c0 + 2 * lane;
+  double z0[D > 0 ? D : GPX_MAXD], z1[D > 0 ? D : GPX_MAXD];
+#pragma unroll
+  for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
+    if (k < d) {
+      z0[k] = c < a.n2 ? a.X2[(long)c * a.ldx2 + k] * a.sb.b[k] : 0.0;
+      z1[k] = c + 1 < a.n2 ? a.X2[(long)(c + 1) * a.ldx2 + k] * a.sb.b[k] : 0.0;
+    }
+  }
+  __syncthreads();
+
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = wid * 16 + rr;
+    const int gr = r0 + r;
+    if (gr >= a.n1) break;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
+      if (k < d) {
+        const double x = sx1[r * d + k];
+        const double d0 = x - z0[k], d1 = x - z1[k];
+        s0 = fma(d0, d0, s0);
+        s1 = fma(d1, d1, s1);
+      }
+    }
+    double k0 = a.sigma * exp(-0.5 * s0);
+    double k1 = a.sigma * exp(-0.5 * s1);
+    if (gr == c) k0 += a.diag_add;
+    if (gr == c + 1) k1 += a.diag_add;
+    if (a.lower) {
+      if (c > gr) k0 = 0.0;
+      if (c + 1 > gr) k1 = 0.0;
+    }
+    double* dst = a.K + (long)gr * a.ldk + c;
+    if (c + 1 < a.n2) {
+      *reinterpret_cast<v2d*>(dst) = (v2d){k0, k1};
+    } else if (c < a.n2) {
+      dst[0] = k0;
+    }
+  }
+}
+
+// K, dsigma, dbeta planes (dense KernelValue.dtheta for small problems).
+struct DthetaArgs {
+  const double* X1; long ldx1; int n1;
+  const double* X2; long ldx2; int n2;
+  int d, nbeta;
+  double sigma;
+  double* K; double* dsigma; double* dbeta; long ld; size_t plane;
+  BetaArg beta;
+};
+
+__global__ void gram_dtheta_kernel(const DthetaArgs a) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= a.n2 || i >= a.n1) return;
+  double s = 0.0, tot = 0.0;
+  double dk[GPX_MAXD];
+  for (int k = 0; k < a.d; ++k) {
+    const double df = a.X1[(long)i * a.ldx1 + k] - a.X2[(long)j * a.ldx2 + k];
+    dk[k] = df * df;
+    s = fma(a.beta.b[k], dk[k], s);
+    tot += dk[k];
+  }
+  const double e = exp(-0.5 * s);
+  const double kv = a.sigma * e;
+  const long o = (long)i * a.ld + j;
+  a.K[o] = kv;
+  a.dsigma[o] = e;  // K / sigma
+  if (a.nbeta == 1) {
+    a.dbeta[o] = -0.5 * tot * kv;
+  } else {
+    for (int k = 0; k < a.d; ++k) a.dbeta[k * a.plane + o] = -0.5 * dk[k] * kv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// grad-trace: sums over the lower triangle of A = alpha alpha^T - Kinv against K and diff_k K.
+// Partials per workgroup -> fixed-order final reduction (bitwise reproducible).
+// ---------------------------------------------------------------------------------------
+struct TraceArgs {
+  const double* X; long ldx; int n; int d; int nbeta;
+  double sigma;
+  const double* alpha; const double* Kinv; long ldk;
+  double* partials;  // [nblocks][nacc]
+  BetaArg sb;        // sqrt(beta_k)
+};
+
+constexpr int TR_MAXACC = GPX_MAXD + 2;
+
+template <int D>
+__global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs a) {
+  __shared__ double sx1[GT_ROWS * GPX_MAXD];
+  __shared__ double sal[GT_ROWS];
+  __shared__ double sred[4][TR_MAXACC];
+  const int d = D > 0 ? D : a.d;
+  const int nacc = 2 + a.nbeta;
+  const int r0 = blockIdx.y * GT_ROWS, c0 = blockIdx.x * GT_COLS;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool skip = c0 > r0 + GT_ROWS - 1;
+
+  // acc[0]: sum A_ii (diag)   acc[1]: sum w A_ij K_ij   acc[2+k]: sum w A_ij K_ij z-diff_k^2
+  double acc[2 + (D > 0 ? D : GPX_MAXD)];
+#pragma unroll
+  for (int q = 0; q < 2 + (D > 0 ? D : GPX_MAXD); ++q) acc[q] = 0.0;
+
+  if (!skip) {
+    for (int e = t; e < GT_ROWS * d; e += GT_THREADS) {
+      const int r = e / d, k = e - r * d;
+      const int gr = r0 + r;
+      sx1[r * d + k] = gr < a.n ? a.X[(long)gr * a.ldx + k] * a.sb.b[k] : 0.0;
+    }
+    if (t < GT_ROWS) sal[t] = (r0 + t) < a.n ? a.alpha[r0 + t] : 0.0;
+    const int c = c0 + 2 * lane;
+    double z0[D > 0 ? D : GPX_MAXD], z1[D > 0 ? D : GPX_MAXD];
+#pragma unroll
+    for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
+      if (k < d) {
+        z0[k] = c < a.n ? a.X[(long)c * a.ldx + k] * a.sb.b[k] : 0.0;
+        z1[k] = c + 1 < a.n ? a.X[(long)(c + 1) * a.ldx + k] * a.sb.b[k] : 0.0;
+      }
+    }
+    const double al0 = c < a.n ? a.alpha[c] : 0.0;
+    const double al1 = c + 1 < a.n ? a.alpha[c + 1] : 0.0;
+    __syncthreads();
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = wid * 16 + rr;
+      const int gr = r0 + r;
+      if (gr >= a.n) break;
+      if (c > gr) continue;  // both columns above the diagonal
+      const double* src = a.Kinv + (long)gr * a.ldk + c;
+      double q0 = 0.0, q1 = 0.0;
+      const bool v1 = (c + 1 <= gr);  // c + 1 < n follows from gr < n
+      if (v1) {
+        const v2d q = *reinterpret_cast<const v2d*>(src);
+        q0 = q[0];
+        q1 = q[1];
+      } else {
+        q0 = src[0];
+      }
+      const double ai = sal[r];
+      double s0 = 0.0, s1 = 0.0;
+      double e0[D > 0 ? D : GPX_MAXD], e1[D > 0 ? D : GPX_MAXD];
+#pragma unroll
+      for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
+        if (k < d) {
+          const double x = sx1[r * d + k];
+          const double d0 = x - z0[k], d1 = x - z1[k];
+          e0[k] = d0 * d0;
+          e1[k] = d1 * d1;
+          s0 += e0[k];
+          s1 += e1[k];
+        }
+      }
+      const double A0 = ai * al0 - q0;
+      const double A1 = v1 ? ai * al1 - q1 : 0.0;
+      const double w0 = (c == gr ? 1.0 : 2.0) * A0 * exp(-0.5 * s0);
+      const double w1 = v1 ? (c + 1 == gr ? 1.0 : 2.0) * A1 * exp(-0.5 * s1) : 0.0;
+      if (c == gr) acc[0] += A0;
+      if (c + 1 == gr) acc[0] += A1;
+      acc[1] += w0 + w1;
+      if (a.nbeta == 1) {
+        acc[2] += w0 * s0 + w1 * s1;  // RBF: sum_k beta (x-x')^2 ; divided by beta on the host
+      } else {
+#pragma unroll
+        for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k)
+          if (k < d) acc[2 + k] += w0 * e0[k] + w1 * e1[k];
+      }
+    }
+  }
+  // wave reduction (fixed order), then 4 waves through LDS
+  for (int q = 0; q < nacc; ++q) {
+    double v = acc[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) sred[wid][q] = v;
+  }
+  __syncthreads();
+  if (t < nacc) a.partials[(size_t)bid * nacc + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
+}
+
+// Final fixed-order reduction of [nblocks][nacc] partials -> out[nacc]; one workgroup.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* partials, size_t nblocks,
+                                                                int nacc, double* out) {
+  __shared__ double sm[1024];
+  const int t = threadIdx.x;
+  for (int q = 0; q < nacc; ++q) {
+    double v = 0.0;
+    for (size_t b = t; b < nblocks; b += 1024) v += partials[b * nacc + q];
+    sm[t] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if (t < s) sm[t] += sm[t + s];
+      __syncthreads();
+    }
+    if (t == 0) out[q] = sm[0];
+    __syncthreads();
+  }
+}
+
+template <typename F>
+void dispatch_d(int d, F&& f) {
+  switch (d) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    default: f(std::integral_constant<int, 0>{}); break;
+  }
+}
+
+}  // namespace
+
+int gpx_gram_launch(hipStream_t s, const double* X1, int n1, long ldx1, const double* X2, int n2,
+                    long ldx2, int d, double sigma, const BetaArg& hb, double diag_add, double* K,
+                    long ldk, int uplo) {
+  if (n1 <= 0 || n2 <= 0) return 0;
+  GramArgs a;
+  a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1;
+  a.X2 = X2; a.ldx2 = ldx2; a.n2 = n2;
+  a.d = d; a.sigma = sigma; a.diag_add = diag_add; a.K = K; a.ldk = ldk; a.lower = uplo == GPX_LOWER;
+  for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(hb.b[k]) : 0.0;
+  dim3 grid((n2 + GT_COLS - 1) / GT_COLS, (n1 + GT_ROWS - 1) / GT_ROWS);
+  dispatch_d(d, [&](auto D) {
+    hipLaunchKernelGGL((gram_kernel<decltype(D)::value>), grid, dim3(GT_THREADS), 0, s, a);
+  });
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+int gpx_gram_dtheta_launch(hipStream_t s, const double* X1, int n1, long ldx1, const double* X2,
+                           int n2, long ldx2, int d, int nbeta, double sigma, const BetaArg& hb,
+                           double* K, double* dsigma, double* dbeta, long ld, size_t plane) {
+  if (n1 <= 0 || n2 <= 0) return 0;
+  DthetaArgs a;
+  a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1; a.X2 = X2; a.ldx2 = ldx2; a.n2 = n2;
+  a.d = d; a.nbeta = nbeta; a.sigma = sigma; a.K = K; a.dsigma = dsigma; a.dbeta = dbeta;
+  a.ld = ld; a.plane = plane; a.beta = hb;
+  dim3 grid((n2 + 255) / 256, n1);
+  hipLaunchKernelGGL(gram_dtheta_kernel, grid, dim3(256), 0, s, a);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+int gpx_grad_trace_launch(hipStream_t s, const double* X, int n, long ldx, int d, int nbeta,
+                          double sigma, const BetaArg& hb, const double* alpha, const double* Kinv,
+                          long ldk, double* red, size_t red_elems, double* out_dev) {
+  TraceArgs a;
+  a.X = X; a.ldx = ldx; a.n = n; a.d = d; a.nbeta = nbeta; a.sigma = sigma;
+  a.alpha = alpha; a.Kinv = Kinv; a.ldk = ldk; a.partials = red;
+  for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(hb.b[k]) : 0.0;
+  dim3 grid((n + GT_COLS - 1) / GT_COLS, (n + GT_ROWS - 1) / GT_ROWS);
+  const size_t nblocks = (size_t)grid.x * grid.y;
+  const int nacc = 2 + nbeta;
+  if (nblocks * nacc > red_elems) {
+    gpx_set_error("grad_trace: reduction scratch too small for n=%d", n);
+    return GPX_ENOMEM;
+  }
+  dispatch_d(d, [&](auto D) {
+    hipLaunchKernelGGL((grad_trace_kernel<decltype(D)::value>), grid, dim3(GT_THREADS), 0, s, a);
+  });
+  GPX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, red, nblocks, nacc, out_dev);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}

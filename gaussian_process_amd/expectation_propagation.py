@@ -1,0 +1,227 @@
+"""GP binary classification by expectation propagation, probit likelihood
+(reference: gaussian_process/expectation_propagation.py).
+
+Per the north star the scalar site-update loop (expectation_propagation.py:72-88) stays on the
+host; every Cholesky / triangular solve / V^T V around it runs on the MI355X through libgpx:
+
+  init + per-sweep recompute   expectation_propagation.py:61-65, 90-94  -> gpx_ep_recompute
+  w, z after convergence       expectation_propagation.py:107-108       -> gpx_gemv + gpx_trsm
+  _posterior                   expectation_propagation.py:115-119       -> gpx_trsm (+ host sums)
+  LML terms t0, t3             expectation_propagation.py:133, 136-137  -> diag(L), gpx_trsm
+  gradient U = L^-1 diag(S)    expectation_propagation.py:162-166       -> gpx_trsm + gpx_gemm
+
+``np.linalg.solve(L, .)`` in the reference is an LU solve of a triangular matrix; the TRSM here
+is the same map up to rounding.  The site order comes from the global NumPy RNG exactly as at
+expectation_propagation.py:70-71.
+"""
+import ctypes as C
+
+import numpy as np
+from scipy.linalg import blas as _blas
+from scipy.special import log_ndtr, ndtr
+from sklearn.base import ClassifierMixin
+from sklearn.utils import check_X_y
+
+from . import _lib
+from .base import BayesEstimator
+from .device import ptr, runtime
+
+eps = 1e-8
+_HALF_LOG_2PI = 0.5 * np.log(2.0 * np.pi)
+
+
+class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
+    """Gaussian process classification with the EP algorithm; drop-in for the reference."""
+
+    def __init__(self, cov):
+        self.cov = cov
+        self.param_bounds = {"cov__" + k: v for k, v in cov.param_bounds.items()}
+
+    def fit(self, X, y):
+        self.Xtr, self.ytr = check_X_y(X, y)
+        self.n, self.dim = self.Xtr.shape
+        K = self.cov(self.Xtr).K
+        self._ep(K)
+
+    def refit(self):
+        self.fit(self.Xtr, self.ytr)
+
+    # ------------------------------------------------------------------ device helpers
+    def _recompute(self, dv, tau, nu):
+        """L = chol(I + S K S), V = L^-1 S K, Sigma = K - V^T V, mu = Sigma nu on the GPU."""
+        rt = dv["rt"]
+        n = dv["n"]
+        dv["tau"][:n].copy_(rt.torch.from_numpy(tau))
+        dv["nu"][:n].copy_(rt.torch.from_numpy(nu))
+        ld = dv["K"].shape[1]
+        rc = rt.lib.gpx_ep_recompute(rt.h, n, ptr(dv["K"]), ld, ptr(dv["tau"]), ptr(dv["nu"]),
+                                     ptr(dv["B"]), ptr(dv["V"]), ptr(dv["Sigma"]), ld, ptr(dv["dinv"]),
+                                     ptr(dv["s"]), ptr(dv["mu"]))
+        _lib.check(rc, "gpx_ep_recompute")
+        Sigma = np.ascontiguousarray(rt.download(dv["Sigma"][:n, :n]))
+        mu = rt.download(dv["mu"][:n]).copy()
+        return Sigma, mu
+
+    def _solve_vec(self, dv, rhs, trans):
+        """L^-1 rhs (trans=0) or L^-T rhs (trans=1) for a host vector, on the GPU."""
+        rt = dv["rt"]
+        n = dv["n"]
+        buf = rt.torch.zeros((n, 2), dtype=rt.torch.float64, device=rt.dev)
+        buf[:, 0].copy_(rt.torch.from_numpy(np.ascontiguousarray(rhs, dtype=np.float64)))
+        _lib.check(rt.lib.gpx_trsm(rt.h, trans, n, 1, ptr(dv["B"]), dv["B"].shape[1], ptr(dv["dinv"]),
+                                   ptr(buf), 2), "gpx_trsm")
+        return rt.download(buf[:, 0]).copy()
+
+    def _solve_mat(self, dv, rhs):
+        """L^-1 rhs for a host matrix (n x m)."""
+        rt = dv["rt"]
+        n = dv["n"]
+        m = rhs.shape[1]
+        buf = rt.upload_matrix(rhs)
+        _lib.check(rt.lib.gpx_trsm(rt.h, 0, n, m, ptr(dv["B"]), dv["B"].shape[1], ptr(dv["dinv"]),
+                                   ptr(buf), buf.shape[1]), "gpx_trsm")
+        return buf
+
+    # ------------------------------------------------------------------ EP
+    def _ep(self, K, fix_index=None, nu_fixed=None, tau_fixed=None, shuffle=True):
+        if fix_index is not None:
+            fix_index = np.array(fix_index, dtype=int)
+            nu_fixed = np.array(nu_fixed, dtype=float)
+            tau_fixed = np.array(tau_fixed, dtype=float)
+            assert len(fix_index) == len(nu_fixed) == len(tau_fixed)
+        else:
+            fix_index = np.array([], dtype=int)
+            nu_fixed = np.array([])
+            tau_fixed = np.array([])
+
+        n = K.shape[0]
+        K = np.asarray(K, dtype=np.float64) + eps * np.eye(n)
+        frozen = np.zeros(n, dtype=bool)
+        frozen[fix_index] = True
+        tau = np.zeros(n)
+        nu = np.zeros(n)
+        tau[fix_index] = tau_fixed
+        nu[fix_index] = nu_fixed
+        y = np.asarray(self.ytr, dtype=np.float64)
+
+        rt = runtime()
+        rt.bind_stream()
+        dv = dict(rt=rt, n=n, K=rt.upload_matrix(K), B=rt.matrix(n, n), V=rt.matrix(n, n),
+                  Sigma=rt.matrix(n, n), dinv=rt.dinv(n), tau=rt.vector(n), nu=rt.vector(n),
+                  s=rt.vector(n), mu=rt.vector(n))
+        Sigma, mu = self._recompute(dv, tau, nu)
+
+        order = np.arange(n)
+        for sweep in range(100):
+            tau_prev = tau.copy()
+            nu_prev = nu.copy()
+            if shuffle:
+                order = np.random.permutation(n)
+            SigmaT = Sigma.T  # same symmetric matrix, Fortran-ordered view for the in-place dger
+            for i in order:
+                if frozen[i]:
+                    continue
+                sii = Sigma[i, i]
+                tau_cav = 1.0 / sii - tau[i]
+                nu_cav = mu[i] / sii - nu[i]
+                dom = tau_cav ** 2 + tau_cav
+                rdom = np.sqrt(dom)
+                z = y[i] * nu_cav / rdom
+                ratio = np.exp(-0.5 * z * z - _HALF_LOG_2PI - log_ndtr(z))
+                mu_hat = nu_cav / tau_cav + y[i] * ratio / rdom
+                var_hat = 1.0 / tau_cav - ratio / dom * (z + ratio)
+                dtau = 1.0 / var_hat - tau_cav - tau[i]
+                tau[i] += dtau
+                nu[i] = mu_hat / var_hat - nu_cav
+                col = Sigma[i].copy()
+                _blas.dger(-dtau / (1.0 + dtau * sii), col, col, a=SigmaT, overwrite_a=1)
+                mu = Sigma @ nu
+            Sigma, mu = self._recompute(dv, tau, nu)
+            if np.sum((tau_prev - tau) ** 2) < eps and np.sum((nu_prev - nu) ** 2) < eps:
+                break
+
+        self.nu_tilde = nu
+        self.tau_tilde = tau
+        self.mu = mu
+        self.Sigma = Sigma
+        self.K = K
+        self.S = np.sqrt(tau).reshape(-1, 1)
+        self._dv = dv
+        self._L_host = None
+        w = self._solve_vec(dv, self.S.ravel() * (K @ nu), trans=0)
+        self.z = self.S.ravel() * self._solve_vec(dv, w, trans=1)
+
+    @property
+    def L(self):
+        """Lower Cholesky factor of I + S K S (downloaded on first use)."""
+        if self._L_host is None:
+            dv = self._dv
+            self._L_host = np.tril(dv["rt"].download(dv["B"][: dv["n"], : dv["n"]]))
+        return self._L_host
+
+    def posterior(self, X):
+        Ks = self.cov(self.Xtr, X).K
+        Kss = self.cov(X, diag=True).K
+        return self._posterior(Ks, Kss)
+
+    def _posterior(self, Ks, Kss):
+        mean = Ks.T @ (self.nu_tilde - self.z)
+        dv = self._dv
+        v = dv["rt"].download(self._solve_mat(dv, self.S * Ks)[: dv["n"], : Ks.shape[1]])
+        return mean, Kss - np.sum(v ** 2, 0)
+
+    def decision_function(self, X):
+        mean, var = self.posterior(X)
+        return ndtr(mean / np.sqrt(1 + var))
+
+    def predict(self, X):
+        return np.sign(self.decision_function(X) - 0.5)
+
+    def log_marginal_likelihood(self, splitted_terms=False):
+        dS = np.diag(self.Sigma)
+        tau_cav = 1 / dS - self.tau_tilde
+        nu_cav = self.mu / dS - self.nu_tilde
+        dv = self._dv
+        rt = dv["rt"]
+        ld = C.c_double(0.0)
+        _lib.check(rt.lib.gpx_logdet(rt.h, dv["n"], ptr(dv["B"]), dv["B"].shape[1], C.byref(ld)),
+                   "gpx_logdet")
+        t0 = -ld.value
+        t1 = 0.5 * np.sum(np.log(1 + self.tau_tilde / tau_cav))
+        Knu = self.K @ self.nu_tilde
+        t2 = 0.5 * self.nu_tilde.dot(Knu)
+        w = self._solve_vec(dv, self.S.ravel() * Knu, trans=0)
+        t3 = -0.5 * w.dot(w)
+        t4 = -0.5 * (self.nu_tilde ** 2).dot(1 / (tau_cav + self.tau_tilde))
+        mu_cav = nu_cav / tau_cav
+        t5 = 0.5 * nu_cav.dot((self.tau_tilde * mu_cav - 2 * self.nu_tilde) / (tau_cav + self.tau_tilde))
+        t6 = np.sum(log_ndtr(self.ytr * mu_cav / np.sqrt(1 + 1 / tau_cav)))
+        terms = (t0, t1, t2, t3, t4, t5, t6)
+        return terms if splitted_terms else sum(terms)
+
+    def grad_log_marginal_likelihood(self, splitted_terms=False):
+        kernel = self.cov(self.Xtr)
+        K_grads = {"cov__" + k: v for k, v in kernel.dtheta.items()}
+        return {k: v if splitted_terms else np.sum(v)
+                for k, v in self._grad_log_marginal_likelihood(kernel.K, K_grads).items()}
+
+    def _grad_log_marginal_likelihood(self, K, K_grads):
+        """expectation_propagation.py:161-167: U = L^-1 diag(S) by TRSM, U^T U by the MFMA GEMM."""
+        dv = self._dv
+        rt = dv["rt"]
+        n = self.n
+        U = self._solve_mat(dv, np.diag(self.S.ravel()))
+        UtU = rt.matrix(n, n)
+        _lib.check(rt.lib.gpx_gemm(rt.h, 1, 0, n, n, n, 1.0, ptr(U), U.shape[1], ptr(U), U.shape[1], 0.0,
+                                   ptr(UtU), UtU.shape[1]), "gpx_gemm")
+        UtU_h = rt.download(UtU[:n, :n])
+        K = K + eps * np.eye(n)
+        b = self.nu_tilde - UtU_h @ (K @ self.nu_tilde)
+        out = {}
+        for name, v in K_grads.items():
+            if v.ndim == 2:
+                out[name] = [0.5 * b.dot(v @ b), 0.5 * np.sum(UtU_h * v.T)]
+            else:  # ARD: one value per dimension
+                out[name] = [0.5 * np.array([b.dot(vk @ b) for vk in v]),
+                             0.5 * np.array([np.sum(UtU_h * vk.T) for vk in v])]
+        return out

@@ -1,0 +1,133 @@
+"""Covariance objects with the reference's interface (reference: gaussian_process/kernels.py).
+
+``RBF(sigma, beta)`` and ``ARD(sigma, beta[d])`` are callables returning
+``KernelValue(K, dtheta)`` exactly as kernels.py:21-46 / 61-88 do, but the matrices are built
+by the HIP Gram kernels of libgpx (``gpx_gram`` / ``gpx_gram_dtheta``).  The estimators do not
+go through ``__call__`` on their hot path: they hand ``kind / sigma / beta`` to the fused C
+entry points, so the (d, n, n) derivative stack only exists when a user asks for ``dtheta``.
+
+Deliberate differences:
+  * inputs are up-cast to float64 (the reference keeps the incoming dtype);
+  * ``ARD(...)(X, diag=True)`` returns ``(sigma*1, zeros((d, n)), ones)``; the reference
+    raises TypeError at kernels.py:84 (bug);
+  * RBF is evaluated from exact differences, not the |x|^2+|y|^2-2xy expansion
+    (kernels.py:34-36); the two agree to ~2e-15 and the diagonal is exactly ``sigma``.
+"""
+from collections import namedtuple
+
+import numpy as np
+from sklearn.base import BaseEstimator
+
+from . import _lib
+from .device import ptr, runtime
+
+KernelValue = namedtuple("KernelValue", ["K", "dtheta"])
+
+_LOWER_BOUND = 1e-5
+
+
+def _as_2d(X, name):
+    X = np.asarray(X)
+    assert X.ndim == 2, "%s must be 2-dimensional" % name
+    return np.ascontiguousarray(X, dtype=np.float64)
+
+
+class _StationaryKernel(BaseEstimator):
+    """Shared device path of RBF and ARD."""
+
+    kind = None
+
+    def _beta_vector(self, dim):
+        raise NotImplementedError
+
+    def gram_params(self, dim):
+        """(kind id, sigma, beta array) as the C ABI wants them."""
+        return _lib.GPX_KIND[self.kind], float(self.sigma), self._beta_vector(dim)
+
+    def _evaluate(self, X1, X2, want_dtheta=True):
+        rt = runtime()
+        rt.bind_stream()
+        lib = rt.lib
+        n1, dim = X1.shape
+        n2 = X2.shape[0]
+        kind, sigma, beta = self.gram_params(dim)
+        beta_arr, beta_p = _lib.host_doubles(beta)
+        dX1 = rt.upload_matrix(X1)
+        dX2 = dX1 if X2 is X1 else rt.upload_matrix(X2)
+        K = rt.matrix(n1, n2)
+        ld = K.shape[1]
+        if not want_dtheta:
+            _lib.check(lib.gpx_gram(rt.h, kind, ptr(dX1), n1, dX1.shape[1], ptr(dX2), n2, dX2.shape[1],
+                                    dim, sigma, beta_p, 0.0, ptr(K), ld, _lib.GPX_FULL), "gpx_gram")
+            return rt.download(K[:n1, :n2]), None, None
+        nplanes = len(beta_arr)
+        dsig = rt.matrix(n1, n2)
+        dbeta = rt.torch.empty((nplanes, max(n1, 1), ld), dtype=rt.torch.float64, device=rt.dev)
+        _lib.check(lib.gpx_gram_dtheta(rt.h, kind, ptr(dX1), n1, dX1.shape[1], ptr(dX2), n2,
+                                       dX2.shape[1], dim, sigma, beta_p, ptr(K), ptr(dsig), ptr(dbeta),
+                                       ld, max(n1, 1) * ld), "gpx_gram_dtheta")
+        return (rt.download(K[:n1, :n2]), rt.download(dsig[:n1, :n2]),
+                rt.download(dbeta[:, :n1, :n2]))
+
+    def _call(self, X1, X2, diag, dim_check=None):
+        X1 = _as_2d(X1, "X1")
+        X2 = X1 if X2 is None else _as_2d(X2, "X2")
+        n1, d1 = X1.shape
+        n2, d2 = X2.shape
+        assert d1 == d2, "X1 and X2 must have the same number of features"
+        if dim_check is not None:
+            assert d1 == dim_check, "input dimension does not match len(beta)"
+        if diag:
+            m = min(n1, n2)
+            nb = len(self._beta_vector(d1))
+            dbeta = np.zeros(m) if self.kind == "rbf" else np.zeros((nb, m))
+            return KernelValue(float(self.sigma) * np.ones(m), {"sigma": np.ones(m), "beta": dbeta})
+        K, dsig, dbeta = self._evaluate(X1, X2)
+        if self.kind == "rbf":
+            dbeta = dbeta[0]
+        return KernelValue(K, {"sigma": dsig, "beta": dbeta})
+
+
+class RBF(_StationaryKernel):
+    """k(x, x') = sigma * exp(-0.5 * beta * |x - x'|^2)   (kernels.py:9-46)."""
+
+    kind = "rbf"
+    param_bounds = {"beta": (_LOWER_BOUND, None), "sigma": (_LOWER_BOUND, None)}
+
+    def __init__(self, sigma=1, beta=1):
+        self.sigma = sigma
+        self.beta = beta
+
+    def _beta_vector(self, dim):
+        return np.array([float(self.beta)])
+
+    def __call__(self, X1, X2=None, diag=False):
+        return self._call(X1, X2, diag)
+
+
+class ARD(_StationaryKernel):
+    """k(x, x') = sigma * exp(-0.5 * sum_k beta_k (x_k - x'_k)^2)   (kernels.py:49-88)."""
+
+    kind = "ard"
+
+    def __init__(self, sigma=1, beta=np.ones(3)):
+        self.sigma = sigma
+        self.beta = np.array(beta)
+        self.dim = len(beta)
+        self.param_bounds = {"sigma": (_LOWER_BOUND, None),
+                             "beta": [(_LOWER_BOUND, None)] * len(beta)}
+
+    def _sync_beta(self):
+        # set_params(cov__beta=ndarray) replaces the attribute (kernels.py:62-64)
+        self.beta = np.array(self.beta)
+        assert self.beta.ndim == 1
+        self.dim = len(self.beta)
+
+    def _beta_vector(self, dim):
+        self._sync_beta()
+        assert dim == self.dim, "input dimension does not match len(beta)"
+        return np.asarray(self.beta, dtype=np.float64)
+
+    def __call__(self, X1, X2=None, diag=False):
+        self._sync_beta()
+        return self._call(X1, X2, diag, dim_check=self.dim)

@@ -1,0 +1,162 @@
+/*
+ * gpx.h -- C ABI of libgpx.so: the MI355X (gfx950) hot path of exact Gaussian-process
+ * regression (RBF/ARD Gram matrix, blocked fp64 Cholesky on MFMA, triangular solves,
+ * log-determinant, K^-1, LML gradient traces, predictive mean/covariance) and the
+ * linear algebra inside the EP classifier.
+ *
+ * The reference (emakryo/gaussian_process, pure Python) has no FFI: its boundary is the
+ * Python object protocol of kernels.py / regression.py.  Each entry point below names
+ * the reference call site (file:line under gaussian_process/) whose arithmetic it
+ * replaces; the Python package gaussian_process_amd is the host-side mirror of that protocol and binds
+ * these symbols with ctypes.
+ *
+ * Conventions
+ *   - every matrix is fp64, ROW-major, with an explicit leading dimension (elements);
+ *     every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - base pointers must be 16-byte aligned and leading dimensions even (the kernels use
+ *     16-byte vector accesses); violations return GPX_EINVAL, they never fault;
+ *   - "lower" matrices are referenced in their lower triangle only (row >= col);
+ *   - the caller owns every buffer; the library allocates nothing in these calls except
+ *     inside gpx_create / gpx_reserve;
+ *   - calls are asynchronous on the handle's stream unless they return a host value
+ *     (info, scalars), in which case they synchronise that stream;
+ *   - return value: 0 ok; >0 LAPACK-style info (order of the leading minor that is not
+ *     positive definite); <0 GPX_E* error, text via gpx_last_error().
+ *   - a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_EINVAL (-1)  /* bad argument (shape, alignment, null pointer)      */
+#define GPX_EHIP (-2)    /* a HIP runtime call failed                           */
+#define GPX_ENOMEM (-3)  /* workspace too small / allocation failed            */
+
+#define GPX_KIND_RBF 0 /* k = sigma * exp(-0.5 * beta    * |x - x'|^2)           kernels.py:9-46  */
+#define GPX_KIND_ARD 1 /* k = sigma * exp(-0.5 * sum_k beta_k (x_k - x'_k)^2)    kernels.py:49-88 */
+
+#define GPX_FULL 0  /* write the whole n1 x n2 matrix                                   */
+#define GPX_LOWER 1 /* square case only: write row >= col, zero inside diagonal blocks   */
+
+#define GPX_NB 128 /* diagonal-block size of the blocked factorisation / dinv layout      */
+
+typedef struct gpx_handle gpx_handle;
+
+/* ---- life cycle ---------------------------------------------------------------------- */
+int gpx_create(gpx_handle** out, int device);
+int gpx_destroy(gpx_handle* h);
+/* stream: a hipStream_t (torch.cuda.current_stream().cuda_stream); NULL = default stream. */
+int gpx_set_stream(gpx_handle* h, void* stream);
+int gpx_synchronize(gpx_handle* h);
+const char* gpx_last_error(void);
+const char* gpx_version(void);
+/* Number of doubles the caller must provide for `dinv` given n (ceil(n/128) blocks of 128x128). */
+size_t gpx_dinv_elems(int n);
+/* Number of doubles of scratch gpx_trtri / gpx_potri need for order n. */
+size_t gpx_trtri_work_elems(int n);
+
+/* ---- Gram matrix and derivatives ------------------------------------------------------ */
+/* K[i][j] = sigma * exp(-0.5 * sum_k beta_k (X1[i][k]-X2[j][k])^2) (+ diag_add if i==j).
+ * Replaces kernels.py:34-37 (RBF, evaluated by exact differences) and kernels.py:77-79 (ARD).
+ * beta_host: d values (ARD) or 1 value (RBF), host memory.  X1: n1 x d (ld = ldx1), X2 likewise;
+ * X2 == NULL means X2 = X1.  uplo = GPX_LOWER requires X2 == NULL or n1 == n2. */
+int gpx_gram(gpx_handle* h, int kind, const double* X1, int n1, int ldx1, const double* X2, int n2,
+             int ldx2, int d, double sigma, const double* beta_host, double diag_add, double* K,
+             int ldk, int uplo);
+/* Dense dK/dtheta planes for the drop-in KernelValue.dtheta (kernels.py:38-39, 80-81):
+ * dsigma = K / sigma (n1 x n2) and dbeta[p] = -0.5 * diff_p * K, p < (kind==ARD ? d : 1), plane
+ * stride `plane` elements.  Small/medium n only: the fused gradient below never forms them. */
+int gpx_gram_dtheta(gpx_handle* h, int kind, const double* X1, int n1, int ldx1, const double* X2,
+                    int n2, int ldx2, int d, double sigma, const double* beta_host, double* K,
+                    double* dsigma, double* dbeta, int ld, size_t plane);
+
+/* ---- Cholesky and friends ------------------------------------------------------------- */
+/* In-place lower Cholesky A = L L^T of the lower triangle of A (n x n), plus the inverses of
+ * the 128x128 diagonal blocks of L in dinv (gpx_dinv_elems(n) doubles).  The strict upper
+ * triangle inside each diagonal block is zeroed; blocks above the diagonal are not touched.
+ * Replaces scipy.linalg.cholesky(lower=True) at regression.py:36,49 and np.linalg.cholesky at
+ * expectation_propagation.py:62,91.  Returns LAPACK info (>0: leading minor not PD). */
+int gpx_potrf(gpx_handle* h, int n, double* A, int lda, double* dinv);
+/* Recompute dinv for a factor L that did not come from gpx_potrf. */
+int gpx_diag_inv(gpx_handle* h, int n, const double* L, int ldl, double* dinv);
+/* B <- L^-1 B (trans = 0) or L^-T B (trans = 1); B is n x nrhs row-major (nrhs may be 1).
+ * Replaces solve_triangular at regression.py:37-38,50, the second half of cho_solve behind
+ * regression.py:61, and np.linalg.solve(L, .) at expectation_propagation.py:63,92,107-108,117,136. */
+int gpx_trsm(gpx_handle* h, int trans, int n, int nrhs, const double* L, int ldl,
+             const double* dinv, double* B, int ldb);
+/* out_host[0] = sum_i log L[i][i]   (regression.py:53, expectation_propagation.py:133). */
+int gpx_logdet(gpx_handle* h, int n, const double* L, int ldl, double* out_host);
+/* L <- L^-1 in place (lower).  work: gpx_trtri_work_elems(n) doubles. */
+int gpx_trtri(gpx_handle* h, int n, double* L, int ldl, const double* dinv, double* work);
+/* Kinv(lower) = W^T W for lower-triangular W = L^-1: together with gpx_trtri this is potri and
+ * replaces scipy.linalg.inv(Ky) at regression.py:60 (SPD route instead of LU). */
+int gpx_lauum(gpx_handle* h, int n, const double* W, int ldw, double* Kinv, int ldk);
+/* C(m x m) <- C - V^T V + diag_add * I, V is n x m.  uplo GPX_FULL or GPX_LOWER.
+ * Replaces regression.py:41-44 and `K - V.T @ V` at expectation_propagation.py:64,93. */
+int gpx_syrk_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double* C, int ldc,
+                 double diag_add, int uplo);
+/* General D = alpha * op(A) op(B) + beta * C on the fp64 MFMA kernel (row-major).
+ * transa/transb: 0 = stored as op, 1 = stored transposed. */
+int gpx_gemm(gpx_handle* h, int transa, int transb, int M, int N, int K, double alpha,
+             const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc);
+/* y(m) = A^T x for A n x m row-major (trans=1) or y(n) = A x (trans=0); fixed-order reduction.
+ * regression.py:39 (mean = a . V), expectation_propagation.py:65,94,116. */
+int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,
+             double* y);
+/* out_host[0] = x . y */
+int gpx_dot(gpx_handle* h, int n, const double* x, const double* y, double* out_host);
+/* Mirror the lower triangle into the upper one (symmetric full matrix for NumPy consumers). */
+int gpx_symmetrize(gpx_handle* h, int n, double* A, int lda);
+/* diag_out[i] = A[i][i] */
+int gpx_diag(gpx_handle* h, int n, const double* A, int lda, double* diag_out);
+
+/* ---- LML gradient --------------------------------------------------------------------- */
+/* out_host[0]      = 0.5 * tr(A)                      d/d(noise)      regression.py:63,70
+ * out_host[1]      = 0.5 * sum_ij A_ij K_ij / sigma   d/d(cov sigma)  kernels.py:39,81
+ * out_host[2 + p]  = 0.5 * sum_ij A_ij (-0.5 diff_p K_ij), p < (ARD ? d : 1)   kernels.py:38,80
+ * with A = alpha alpha^T - Kinv (regression.py:62), Kinv given in its LOWER triangle and K,
+ * diff recomputed from X on the fly: the (d,n,n) tensor of kernels.py:80 never exists. */
+int gpx_grad_trace(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
+                   const double* beta_host, const double* alpha, const double* Kinv, int ldk,
+                   double* out_host);
+
+/* ---- fused estimator paths ------------------------------------------------------------ */
+/* One evaluation of (LML, grad) = regression.py:46-76 from one Gram + one factorisation:
+ *   Ky (n x ldk, overwritten: L^-1 on exit), Kinv (n x ldk, Ky^-1 lower on exit),
+ *   dinv (gpx_dinv_elems(n)), vec (4*n doubles of scratch).
+ *   alpha_out (n) = Ky^-1 y, a_out (n) = L^-1 y (either may be NULL).
+ *   lml_host[0] = LML; grad_host[0..1+nb] as gpx_grad_trace (NULL = skip the gradient, in
+ *   which case Ky holds L on exit and Kinv is not touched). */
+int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, int d,
+                     double sigma, const double* beta_host, double noise, const double* y,
+                     double* Ky, double* Kinv, int ldk, double* dinv, double* vec,
+                     double* alpha_out, double* a_out, double* lml_host, double* grad_host);
+/* regression.py:31-44 given the factor L (lower) of Ky and its dinv:
+ *   V (n x ldv >= m) scratch, mean (m), cov (m x ldc) = K(Xs,Xs) - V^T V + noise I (full matrix,
+ *   or only its lower triangle + mirrored when full_cov=1; full_cov=0 fills only var (m)). */
+int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
+                    const double* beta_host, double noise, const double* y, const double* L,
+                    int ldl, const double* dinv, const double* Xs, int m, int ldxs, double* V,
+                    int ldv, double* vec, double* mean, double* cov, int ldc, double* var,
+                    int full_cov);
+
+/* ---- EP inner linear algebra (expectation_propagation.py:61-65, 90-94) ------------------ */
+/* B = I + (s s^T) o K  (lower) and SK = diag(s) K (full), s = sqrt(tau). */
+int gpx_ep_scale(gpx_handle* h, int n, const double* K, int ldk, const double* s, double* B,
+                 int ldb, double* SK, int ldsk);
+/* One recompute: L = chol(I + S K S) (in Bbuf), V = L^-1 S K (in Vbuf), Sigma = K - V^T V (full,
+ * symmetric), mu = Sigma nu.  Returns potrf info. */
+int gpx_ep_recompute(gpx_handle* h, int n, const double* K, int ldk, const double* tau,
+                     const double* nu, double* Bbuf, double* Vbuf, double* Sigma, int ld,
+                     double* dinv, double* svec, double* mu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

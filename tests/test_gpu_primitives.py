@@ -1,0 +1,219 @@
+"""GPU parity of the libgpx primitives, called through the C ABI (ctypes), against NumPy/SciPy
+and the oracle on the same seeded inputs.  Tolerances: fp64, relative (Frobenius) <= 1e-12 for
+single kernels unless the conditioning of the test problem says otherwise (stated inline)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from conftest import relerr
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from gaussian_process_amd.device import runtime
+    r = runtime()
+    r.bind_stream()
+    return r
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def up(rt, a):
+    return rt.upload_matrix(a)
+
+
+def down(rt, t, r, c):
+    return rt.download(t[:r, :c]).copy()
+
+
+def ok(rc):
+    from gaussian_process_amd import _lib
+    _lib.check(rc, "gpx call")
+
+
+def spd(n, seed, cond_shift=1.0):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n + 3))
+    return A @ A.T / n + cond_shift * np.eye(n)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (128, 128, 16), (130, 70, 33), (257, 300, 129), (64, 1, 200)])
+def test_gemm_layouts(rt, ta, tb, M, N, K):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K + ta * 2 + tb)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    Cm = rng.standard_normal((M, N))
+    dA, dB, dC = up(rt, A), up(rt, B), up(rt, Cm)
+    ok(rt.lib.gpx_gemm(rt.h, ta, tb, M, N, K, 0.75, P(dA), dA.shape[1], P(dB), dB.shape[1], -0.5,
+                       P(dC), dC.shape[1]))
+    ref = 0.75 * ((A.T if ta else A) @ (B.T if tb else B)) - 0.5 * Cm
+    assert relerr(down(rt, dC, M, N), ref) < 1e-13
+
+
+def test_gemm_identity_asymmetric(rt):
+    """A = I with an asymmetric B pins the MFMA C/D lane map (row/col not swapped)."""
+    n = 128
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    dA, dB, dC = up(rt, np.eye(n)), up(rt, B), up(rt, np.zeros((n, n)))
+    ok(rt.lib.gpx_gemm(rt.h, 0, 0, n, n, n, 1.0, P(dA), dA.shape[1], P(dB), dB.shape[1], 0.0, P(dC),
+                       dC.shape[1]))
+    assert np.array_equal(down(rt, dC, n, n), B)
+
+
+# ----------------------------------------------------------------------------- Gram
+@pytest.mark.parametrize("kind,d", [("rbf", 1), ("rbf", 3), ("ard", 2), ("ard", 8), ("ard", 5)])
+@pytest.mark.parametrize("n1,n2", [(1, 1), (15, 50), (129, 257), (300, 300)])
+def test_gram_matches_oracle(rt, kind, d, n1, n2):
+    rng = np.random.default_rng(n1 + 7 * n2 + d)
+    X1 = rng.uniform(-3, 3, (n1, d))
+    X2 = rng.uniform(-3, 3, (n2, d))
+    beta = rng.uniform(0.05, 2.0, d if kind == "ard" else 1)
+    sigma = 1.7
+    from gaussian_process_amd import _lib
+    barr, bp = _lib.host_doubles(beta)
+    dX1, dX2 = up(rt, X1), up(rt, X2)
+    K = rt.matrix(n1, n2)
+    ok(rt.lib.gpx_gram(rt.h, _lib.GPX_KIND[kind], P(dX1), n1, dX1.shape[1], P(dX2), n2, dX2.shape[1], d,
+                       sigma, bp, 0.0, P(K), K.shape[1], 0))
+    Ko, _, _ = O.cov(kind, X1, X2, sigma, beta)
+    assert relerr(down(rt, K, n1, n2), Ko) < 1e-13
+    # square, lower, with the noise on the diagonal
+    Kl = rt.matrix(n1, n1)
+    Kl.fill_(float("nan"))
+    ok(rt.lib.gpx_gram(rt.h, _lib.GPX_KIND[kind], P(dX1), n1, dX1.shape[1], None, 0, 0, d, sigma, bp,
+                       0.25, P(Kl), Kl.shape[1], 1))
+    Ks, _, _ = O.cov(kind, X1, None, sigma, beta)
+    got = down(rt, Kl, n1, n1)
+    assert relerr(np.tril(got), np.tril(Ks + 0.25 * np.eye(n1))) < 1e-13
+    # inside each 128-wide diagonal block the strict upper triangle is zero
+    for b0 in range(0, n1, 128):
+        blk = got[b0:b0 + 128, b0:b0 + 128]
+        assert np.all(np.triu(blk, 1) == 0.0)
+
+
+def test_gram_dtheta_matches_oracle(rt):
+    from gaussian_process_amd import RBF, ARD
+    rng = np.random.default_rng(5)
+    X1, X2 = rng.uniform(-3, 3, (70, 3)), rng.uniform(-3, 3, (45, 3))
+    kv = ARD(sigma=1.3, beta=[0.2, 1.0, 2.5])(X1, X2)
+    K, ds, db = O.ard_cov(X1, X2, 1.3, np.array([0.2, 1.0, 2.5]), want_grad=True)
+    assert relerr(kv.K, K) < 1e-13 and relerr(kv.dtheta["sigma"], ds) < 1e-13
+    assert kv.dtheta["beta"].shape == (3, 70, 45) and relerr(kv.dtheta["beta"], db) < 1e-13
+    kv = RBF(sigma=0.7, beta=0.4)(X1)
+    K, ds, db = O.rbf_cov(X1, None, 0.7, 0.4, want_grad=True)
+    assert relerr(kv.K, K) < 1e-13 and relerr(kv.dtheta["sigma"], ds) < 1e-13
+    assert kv.dtheta["beta"].shape == (70, 70)
+    assert np.abs(kv.dtheta["beta"] - db).max() < 1e-13 * np.abs(db).max()
+    assert list(kv.dtheta) == ["sigma", "beta"]
+
+
+# ----------------------------------------------------------------------------- Cholesky family
+@pytest.mark.parametrize("n", [1, 2, 15, 100, 128, 129, 255, 300, 1000, 2050])
+def test_potrf_trsm_trtri_lauum(rt, n):
+    A = spd(n, n)
+    dA = up(rt, A)
+    dinv = rt.dinv(n)
+    ld = dA.shape[1]
+    ok(rt.lib.gpx_potrf(rt.h, n, P(dA), ld, P(dinv)))
+    L = np.tril(down(rt, dA, n, n))
+    Lref = sla.cholesky(A, lower=True)
+    assert relerr(L, Lref) < 1e-13
+    assert relerr(L @ L.T, A) < 1e-14
+    ldet = C.c_double()
+    ok(rt.lib.gpx_logdet(rt.h, n, P(dA), ld, C.byref(ldet)))
+    assert abs(ldet.value - np.log(np.diag(Lref)).sum()) <= 1e-12 * max(1.0, abs(ldet.value))
+    # dinv from scratch equals the one potrf produced
+    dinv2 = rt.dinv(n)
+    ok(rt.lib.gpx_diag_inv(rt.h, n, P(dA), ld, P(dinv2)))
+    assert relerr(rt.download(dinv2), rt.download(dinv)) < 1e-13
+    rng = np.random.default_rng(n)
+    for nrhs in (1, 3, 200):
+        B = rng.standard_normal((n, nrhs))
+        for trans in (0, 1):
+            dB = up(rt, B)
+            ok(rt.lib.gpx_trsm(rt.h, trans, n, nrhs, P(dA), ld, P(dinv), P(dB), dB.shape[1]))
+            ref = sla.solve_triangular(Lref, B, lower=True, trans="T" if trans else "N")
+            assert relerr(down(rt, dB, n, nrhs), ref) < 1e-12
+    # potri = trtri + lauum
+    work = rt.vector(int(rt.lib.gpx_trtri_work_elems(n)))
+    ok(rt.lib.gpx_trtri(rt.h, n, P(dA), ld, P(dinv), P(work)))
+    W = np.tril(down(rt, dA, n, n))
+    assert relerr(W, np.linalg.inv(Lref)) < 1e-12
+    Kinv = rt.matrix(n, n)
+    ok(rt.lib.gpx_lauum(rt.h, n, P(dA), ld, P(Kinv), Kinv.shape[1]))
+    assert relerr(np.tril(down(rt, Kinv, n, n)), np.tril(np.linalg.inv(A))) < 1e-12
+    ok(rt.lib.gpx_symmetrize(rt.h, n, P(Kinv), Kinv.shape[1]))
+    assert relerr(down(rt, Kinv, n, n), np.linalg.inv(A)) < 1e-12
+
+
+@pytest.mark.parametrize("n,bad", [(10, 4), (300, 0), (300, 131), (300, 299)])
+def test_potrf_reports_leading_minor(rt, n, bad):
+    """LAPACK info semantics: first leading minor that is not positive definite (regression.py:36)."""
+    A = spd(n, 3)
+    A[bad, bad] = -1.0
+    dA = up(rt, A)
+    rc = rt.lib.gpx_potrf(rt.h, n, P(dA), dA.shape[1], P(rt.dinv(n)))
+    with pytest.raises(np.linalg.LinAlgError):
+        sla.cholesky(A, lower=True)
+    assert rc == bad + 1
+    from gaussian_process_amd import _lib
+    with pytest.raises(np.linalg.LinAlgError, match="%d-th leading minor" % (bad + 1)):
+        _lib.check(rc, "potrf")
+
+
+def test_bad_arguments_are_rejected_not_faulted(rt):
+    from gaussian_process_amd import _lib
+    A = up(rt, spd(8, 1))
+    assert rt.lib.gpx_potrf(rt.h, 8, P(A), 7, P(rt.dinv(8))) == -1      # odd / too small ld
+    assert rt.lib.gpx_potrf(rt.h, 8, C.c_void_p(A.data_ptr() + 8), 32, P(rt.dinv(8))) == -1  # misaligned
+    assert rt.lib.gpx_potrf(rt.h, 8, None, 32, P(rt.dinv(8))) == -1
+    assert "potrf" in _lib.last_error()
+    assert rt.lib.gpx_potrf(rt.h, 0, None, 0, None) == 0                  # empty input is fine
+
+
+@pytest.mark.parametrize("n,m", [(300, 129), (1000, 64), (5, 3)])
+def test_syrk_sub_gemv(rt, n, m):
+    rng = np.random.default_rng(n + m)
+    V = rng.standard_normal((n, m))
+    Cm = spd(m, 2)
+    dV, dC = up(rt, V), up(rt, Cm)
+    ok(rt.lib.gpx_syrk_sub(rt.h, n, m, P(dV), dV.shape[1], P(dC), dC.shape[1], 0.3, 0))
+    assert relerr(down(rt, dC, m, m), Cm - V.T @ V + 0.3 * np.eye(m)) < 1e-13
+    x = rng.standard_normal(n)
+    dx, dy = rt.upload_vector(x), rt.vector(m)
+    ok(rt.lib.gpx_gemv(rt.h, 1, n, m, P(dV), dV.shape[1], P(dx), P(dy)))
+    assert relerr(rt.download(dy[:m]), V.T @ x) < 1e-13
+    z = rng.standard_normal(m)
+    dz, dw = rt.upload_vector(z), rt.vector(n)
+    ok(rt.lib.gpx_gemv(rt.h, 0, n, m, P(dV), dV.shape[1], P(dz), P(dw)))
+    assert relerr(rt.download(dw[:n]), V @ z) < 1e-13
+
+
+@pytest.mark.parametrize("kind,d,n", [("ard", 8, 300), ("rbf", 2, 129), ("ard", 3, 64)])
+def test_grad_trace_matches_oracle(rt, kind, d, n):
+    from gaussian_process_amd import _lib
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-3, 3, (n, d))
+    y = rng.standard_normal(n)
+    beta = rng.uniform(0.05, 1.0, d if kind == "ard" else 1)
+    sigma, noise = 1.4, 0.1
+    g_o, alpha = O.gpr_grad(kind, X, y, sigma, beta, noise)
+    K, _, _ = O.cov(kind, X, None, sigma, beta)
+    Kinv = np.linalg.inv(K + noise * np.eye(n))
+    dX, dal, dKi = up(rt, X), rt.upload_vector(alpha), up(rt, np.tril(Kinv))
+    barr, bp = _lib.host_doubles(beta)
+    out = (C.c_double * (2 + len(barr)))()
+    ok(rt.lib.gpx_grad_trace(rt.h, _lib.GPX_KIND[kind], P(dX), n, dX.shape[1], d, sigma, bp, P(dal),
+                             P(dKi), dKi.shape[1], C.cast(out, C.POINTER(C.c_double))))
+    got = np.array(list(out))
+    ref = np.concatenate([g_o["sigma"], g_o["cov__sigma"], g_o["cov__beta"]])
+    assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()

@@ -1,0 +1,142 @@
+"""GPU parity of the drop-in estimators against the golden fixtures produced by the real
+reference (tests/golden/*.npz) and against the oracle.  These read like the reference's own
+usage (examples/*.ipynb): same constructors, same method names, same return shapes.
+
+Tolerance (north star): LML, alpha, predictive mean / covariance within 1e-9 relative, fp64."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def make_gp(g):
+    from gaussian_process_amd import GaussianProcessRegression, RBF, ARD
+    if str(g["kind"]) == "ard":
+        cov = ARD(sigma=float(g["cov_sigma"]), beta=g["cov_beta"])
+    else:
+        cov = RBF(sigma=float(g["cov_sigma"]), beta=float(g["cov_beta"][0]))
+    gp = GaussianProcessRegression(cov=cov, sigma=float(g["noise"]))
+    assert gp.fit(g["X"], g["y"]) is None      # regression.py:18-23 returns None
+    return gp
+
+
+@pytest.mark.parametrize("name", ["g1_rbf1d_n15", "g1_rbf1d_n200", "g2_ard2d", "g3_ard8_n256",
+                                  "g3_ard8_n1024", "g3_ard8_n4096"])
+def test_fixed_theta_matches_reference(name):
+    g = load_golden(name)
+    gp = make_gp(g)
+    lml = gp.log_marginal_likelihood()
+    assert isinstance(lml, float)
+    assert abs(lml - float(g["lml"])) <= TOL * abs(float(g["lml"]))
+    assert relerr(gp.alpha_(), g["alpha"]) < TOL
+    mean, cov = gp.predict_with_variance(g["Xs"])
+    m = g["Xs"].shape[0]
+    assert mean.shape == (m,) and cov.shape == (m, m)
+    assert relerr(mean, g["mean"]) < TOL
+    assert relerr(cov, g["pcov"]) < TOL
+    assert relerr(gp.predict(g["Xs"]), g["mean"]) < TOL
+    mean2, var = gp.predict_with_variance(g["Xs"], full_cov=False)
+    assert relerr(var, np.diagonal(g["pcov"])) < 1e-8
+    grads = gp.grad_log_marginal_likelihood()
+    assert list(grads) == ["sigma", "cov__sigma", "cov__beta"]
+    assert grads["sigma"].shape == (1,) and grads["cov__sigma"].shape == (1,)
+    assert grads["cov__beta"].shape == g["grad_cov_beta"].shape
+    scale = max(np.abs(g["grad_sigma"]).max(), np.abs(g["grad_cov_sigma"]).max(),
+                np.abs(g["grad_cov_beta"]).max())
+    # traces of A = alpha alpha^T - Ky^-1 against dK: cancellation => relative to the largest
+    for k, ref in (("sigma", g["grad_sigma"]), ("cov__sigma", g["grad_cov_sigma"]),
+                   ("cov__beta", g["grad_cov_beta"])):
+        assert np.abs(grads[k] - ref).max() <= 1e-8 * scale, k
+    # LML again after the gradient pass (cached) and prediction after it (re-factorisation)
+    assert gp.log_marginal_likelihood() == lml
+    assert relerr(gp.predict(g["Xs"]), g["mean"]) < TOL
+
+
+def test_regression_1d_notebook_flow():
+    """examples/regression_1d.ipynb cells 2-4: fit, predict, empirical_bayes, LML sweep via set_params."""
+    from gaussian_process_amd import GaussianProcessRegression, RBF
+    g = load_golden("g1_rbf1d_n15")
+    gp = GaussianProcessRegression(cov=RBF(), sigma=0.1)
+    gp.fit(g["X"], g["y"])
+    assert abs(gp.log_marginal_likelihood() - (-11.80896075441085)) < 1e-9
+    gp.empirical_bayes()
+    assert abs(gp.log_marginal_likelihood() - float(g["eb_lml"])) < 1e-5
+    assert np.allclose([gp.cov.beta, gp.cov.sigma, gp.sigma],
+                       [float(g["eb_beta"]), float(g["eb_cov_sigma"]), float(g["eb_noise"])], rtol=1e-3)
+    vals = []
+    for b in (0.2, 1.0):
+        for s in (0.05, 0.5):
+            gp.set_params(cov__beta=b, sigma=s)
+            vals.append(gp.log_marginal_likelihood())
+            lo, _, _ = O.gpr_lml("rbf", g["X"], g["y"], gp.cov.sigma, b, s)
+            assert abs(vals[-1] - lo) <= TOL * abs(lo)
+    assert len(set(vals)) == 4
+    r2 = gp.score(g["X"], g["y"])        # RegressorMixin
+    assert np.isfinite(r2)
+
+
+def test_ard_2d_notebook_empirical_bayes():
+    """examples/ARD_regression_2d.ipynb: RMSE 0.28596 -> 0.20874, beta -> [1.1465, 3.7085]."""
+    from gaussian_process_amd import GaussianProcessRegression, ARD
+    g = load_golden("g2_ard2d")
+    gp = GaussianProcessRegression(cov=ARD(beta=[1, 1]))
+    gp.fit(g["X"], g["y"])
+    rmse0 = np.sqrt(np.mean((gp.predict(g["Xs"]) - g["yte"]) ** 2))
+    assert abs(rmse0 - 0.285960216844) < 1e-8
+    gp.fit(g["X"], g["y"], empirical_bayes=True)
+    rmse1 = np.sqrt(np.mean((gp.predict(g["Xs"]) - g["yte"]) ** 2))
+    assert abs(rmse1 - 0.208740245085) < 1e-4
+    assert np.allclose(gp.cov.beta, [1.14651806, 3.7085029], rtol=1e-4)
+    assert abs(gp.log_marginal_likelihood() - float(g["eb_lml"])) < 1e-5 * abs(float(g["eb_lml"]))
+
+
+def test_not_positive_definite_raises_linalgerror():
+    from gaussian_process_amd import GaussianProcessRegression, RBF
+    X = np.zeros((6, 1))
+    gp = GaussianProcessRegression(cov=RBF(), sigma=-2.0)   # K + sigma I indefinite
+    gp.fit(X, np.arange(6.0))
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.log_marginal_likelihood()
+
+
+def test_bad_inputs_raise_like_reference():
+    from gaussian_process_amd import GaussianProcessRegression, RBF
+    gp = GaussianProcessRegression(cov=RBF())
+    with pytest.raises(ValueError):
+        gp.fit(np.zeros((4, 1)), np.array([0.0, np.nan, 1.0, 2.0]))   # check_X_y
+    with pytest.raises(ValueError):
+        gp.fit(np.zeros(4), np.zeros(4))
+
+
+@pytest.mark.parametrize("n", [8192])
+def test_large_size_properties(n):
+    """Beyond the sizes the reference can run: size-independent properties.
+    ||Ky alpha - y|| / ||y||, ||L L^T - Ky||_F / ||Ky||_F on sampled rows, LML against the oracle
+    restatement, gradient by central finite differences of the GPU LML."""
+    from gaussian_process_amd import GaussianProcessRegression, ARD
+    X, y, Xs, beta = O.synthetic_ard(n, m=300, d=8, seed=1, noise=0.1)
+    gp = GaussianProcessRegression(cov=ARD(sigma=1.0, beta=beta), sigma=0.1)
+    gp.fit(X, y)
+    lml = gp.log_marginal_likelihood()
+    alpha = gp.alpha_()
+    K, _, _ = O.ard_cov(X, None, 1.0, beta)
+    K[np.diag_indices_from(K)] += 0.1
+    assert np.linalg.norm(K @ alpha - y) / np.linalg.norm(y) < 1e-11
+    lml_o, _, L = O.gpr_lml("ard", X, y, 1.0, beta, 0.1)
+    assert abs(lml - lml_o) <= TOL * abs(lml_o)
+    assert relerr(alpha, O.gpr_alpha(L, y)) < TOL
+    mean, cov = gp.predict_with_variance(Xs)
+    mo, co = O.gpr_predict("ard", X, y, Xs, 1.0, beta, 0.1, L=L)
+    assert relerr(mean, mo) < TOL and relerr(cov, co) < TOL
+    assert np.allclose(cov, cov.T, rtol=0, atol=0)
+    g = gp.grad_log_marginal_likelihood()
+    h = 1e-4
+    gp.set_params(sigma=0.1 + h)
+    up_ = gp.log_marginal_likelihood()
+    gp.set_params(sigma=0.1 - h)
+    dn = gp.log_marginal_likelihood()
+    assert abs((up_ - dn) / (2 * h) - g["sigma"][0]) < 1e-4 * abs(g["sigma"][0])
