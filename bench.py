@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: exact GP fit+predict at n=65536, d=8 (synthetic ARD) on MI355X.
+
+A "step" is one pass of the hot path over one synthetic data set already resident in HBM:
+  Gram (Ky = K + noise I, lower)            kernels.py:77-79 / regression.py:47-48
+  potrf (L = chol(Ky))                      regression.py:36,49
+  a = L^-1 y, alpha = L^-T a, LML           regression.py:50-55, 61
+  predict: k*, V = L^-1 k*, mean, cov       regression.py:31-44      (m test points)
+  gradient: L^-1, Ky^-1 = L^-T L^-1, traces regression.py:57-76
+`value` is the potrf throughput n^3/3 / t_potrf in TFLOP/s (whole job: all GPUs), `ms_per_step`
+the fit+predict wall time of the whole step.  The roofline object prices the potrf phase (its
+flops run in the fp64 MFMA GEMM kernel) against the fp64 matrix peak, live, from HIP events on
+the stream the kernels run on.  cpu_baseline times the oracle (NumPy/SciPy restatement of the
+reference) on a bounded sample on the host cores.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class Timer:
+    """HIP events on torch's current stream (the stream libgpx is bound to)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.marks = []
+
+    def mark(self, name):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((name, e))
+
+    def stages(self):
+        self.torch.cuda.synchronize()
+        out = {}
+        for (n0, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+def single_gpu_step(rt, lib, bufs, cfg, timer, check):
+    """One fit+predict pass through the C ABI primitives (same kernels as the fused entry points,
+    called one by one so every stage can be bracketed by events)."""
+    from gaussian_process_amd import _lib
+    n, m, d = cfg["n"], cfg["m"], cfg["d"]
+    X, y, Xs, Ky, Kinv, dinv, V, cov, vec2, a_vec, al_vec, mean = (
+        bufs[k] for k in ("X", "y", "Xs", "Ky", "Kinv", "dinv", "V", "cov", "vec2", "a", "alpha", "mean"))
+    ld = Ky.shape[1]
+    beta_arr, beta_p = _lib.host_doubles(cfg["beta"])
+    kind = _lib.GPX_KIND["ard"]
+    sig, noise = cfg["sigma"], cfg["noise"]
+    timer.mark("start")
+    check(lib.gpx_gram(rt.h, kind, P(X), n, X.shape[1], None, 0, 0, d, sig, beta_p, noise, P(Ky), ld, 1), "gram")
+    timer.mark("gram")
+    check(lib.gpx_potrf(rt.h, n, P(Ky), ld, P(dinv)), "potrf")
+    timer.mark("potrf")
+    vec2.zero_()
+    vec2[:, 0].copy_(y[:n])
+    check(lib.gpx_trsm(rt.h, 0, n, 1, P(Ky), ld, P(dinv), P(vec2), 2), "trsv")
+    a_vec[:n].copy_(vec2[:, 0])
+    check(lib.gpx_trsm(rt.h, 1, n, 1, P(Ky), ld, P(dinv), P(vec2), 2), "trsv^T")
+    al_vec[:n].copy_(vec2[:, 0])
+    aa, ldet = C.c_double(), C.c_double()
+    check(lib.gpx_dot(rt.h, n, P(a_vec), P(a_vec), C.byref(aa)), "dot")
+    check(lib.gpx_logdet(rt.h, n, P(Ky), ld, C.byref(ldet)), "logdet")
+    lml = -0.5 * aa.value - ldet.value - 0.5 * n * np.log(2 * np.pi)
+    timer.mark("solve_lml")
+    check(lib.gpx_gpr_predict(rt.h, kind, P(X), n, X.shape[1], d, sig, beta_p, noise, P(y), P(Ky), ld,
+                              P(dinv), P(Xs), m, Xs.shape[1], P(V), V.shape[1], P(bufs["vec4"]), P(mean),
+                              P(cov), cov.shape[1], None, 1), "predict")
+    timer.mark("predict")
+    check(lib.gpx_trtri(rt.h, n, P(Ky), ld, P(dinv), P(Kinv)), "trtri")
+    timer.mark("trtri")
+    check(lib.gpx_lauum(rt.h, n, P(Ky), ld, P(Kinv), ld), "lauum")
+    timer.mark("lauum")
+    grad = (C.c_double * (2 + d))()
+    check(lib.gpx_grad_trace(rt.h, kind, P(X), n, X.shape[1], d, sig, beta_p, P(al_vec), P(Kinv), ld,
+                             C.cast(grad, C.POINTER(C.c_double))), "grad_trace")
+    timer.mark("grad_trace")
+    return lml, np.array(list(grad))
+
+
+def residual_checks(rt, lib, bufs, cfg, check):
+    """Size-independent parity properties at the full size: ||Ky alpha - y|| / ||y|| with Ky rebuilt
+    by the Gram kernel (full matrix) and applied by gpx_gemv."""
+    from gaussian_process_amd import _lib
+    n, d = cfg["n"], cfg["d"]
+    X, y, Ky = bufs["X"], bufs["y"], bufs["Ky"]
+    beta_arr, beta_p = _lib.host_doubles(cfg["beta"])
+    ld = Ky.shape[1]
+    check(lib.gpx_gram(rt.h, _lib.GPX_KIND["ard"], P(X), n, X.shape[1], None, 0, 0, d, cfg["sigma"], beta_p,
+                       cfg["noise"], P(Ky), ld, 0), "gram")
+    r = rt.vector(n)
+    check(lib.gpx_gemv(rt.h, 0, n, n, P(Ky), ld, P(bufs["alpha"]), P(r)), "gemv")
+    res = (r[:n] - y[:n]).norm().item() / y[:n].norm().item()
+    return res
+
+
+def cpu_baseline(n_cpu, m_cpu):
+    """The oracle (CPU restatement of the reference's path) on a bounded sample, all host cores the
+    BLAS is given.  Reports potrf GFLOP/s-equivalent in the metric's unit (TFLOP/s)."""
+    from oracle import gp_oracle as O
+    import scipy.linalg as sla
+    X, y, Xs, beta = O.synthetic_ard(n_cpu, m=m_cpu, d=8, seed=0, noise=0.1)
+    t0 = time.perf_counter()
+    K, _, _ = O.ard_cov(X, None, 1.0, beta)
+    K[np.diag_indices_from(K)] += 0.1
+    t1 = time.perf_counter()
+    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    t2 = time.perf_counter()
+    lml, a, _ = O.gpr_lml("ard", X, y, 1.0, beta, 0.1, L=L)
+    mean, cov = O.gpr_predict("ard", X, y, Xs, 1.0, beta, 0.1, L=L)
+    t3 = time.perf_counter()
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        infos = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if infos:
+            threads = max(i["num_threads"] for i in infos)
+    except Exception:
+        pass
+    return {"value": round(n_cpu ** 3 / 3 / (t2 - t1) / 1e12, 5), "unit": "TFLOP/s", "cores": int(threads),
+            "kind": "port",
+            "sample": "oracle (NumPy/SciPy restatement) at n=%d d=8 m=%d: gram %.2fs, cholesky %.2fs, "
+                      "lml+predict %.2fs; value = n^3/3 / cholesky time" % (n_cpu, m_cpu, t1 - t0, t2 - t1, t3 - t2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=65536)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--cpu-n", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        from gaussian_process_amd import dist_bench
+        return dist_bench.main(args, rank, local_rank, world)
+
+    torch.cuda.set_device(0)
+    from gaussian_process_amd import _lib
+    from gaussian_process_amd.device import runtime
+    from oracle import gp_oracle as O     # input generator + cpu_baseline only
+    rt = runtime(0)
+    rt.bind_stream()
+    lib = rt.lib
+    n, m, d = args.n, args.m, 8
+
+    def check(rc, what):
+        _lib.check(rc, what)
+
+    X, y, Xs, beta = O.synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
+    cfg = dict(n=n, m=m, d=d, beta=beta, sigma=1.0, noise=0.1)
+    bufs = dict(X=rt.upload_matrix(X), y=rt.upload_vector(y), Xs=rt.upload_matrix(Xs),
+                Ky=rt.matrix(n, n), Kinv=rt.matrix(n, n), dinv=rt.dinv(n), V=rt.matrix(n, m),
+                cov=rt.matrix(m, m), vec2=torch.zeros((n, 2), dtype=torch.float64, device=rt.dev),
+                vec4=rt.vector(4 * n), a=rt.vector(n), alpha=rt.vector(n), mean=rt.vector(m))
+    for _ in range(args.warmup):
+        single_gpu_step(rt, lib, bufs, cfg, Timer(torch), check)
+    torch.cuda.synchronize()
+    timers = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tm = Timer(torch)
+        lml, grad = single_gpu_step(rt, lib, bufs, cfg, tm, check)
+        timers.append(tm)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms_per_step = 1e3 * wall / args.steps
+    stages = {}
+    for tm in timers:
+        for k, v in tm.stages().items():
+            stages[k] = stages.get(k, 0.0) + v / args.steps
+    potrf_s = stages["potrf"] / 1e3
+    potrf_tflops = n ** 3 / 3 / potrf_s / 1e12
+    total_flops = n ** 3 / 3 + n * n * m + n * m * m + 2 * n ** 3 / 3
+    gram_bytes = 4.0 * n * (n + 1) + 8.0 * n * d       # lower triangle written + X read
+    res = residual_checks(rt, lib, bufs, cfg, check)
+    mean_h = rt.download(bufs["mean"][:m])
+    out = {
+        "metric": "GP fit+predict wall time & potrf fp64 TFLOP/s at n=%d d=8" % n,
+        "value": round(potrf_tflops, 3), "unit": "TFLOP/s (potrf, n^3/3 flops)",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "synthetic ARD regression n=%d d=8 m=%d, noise 0.1 (BASELINE configs[3]; "
+                               "fits one GPU)" % (n, m), "parallelism": "1 GPU"},
+        "fit_predict_wall_s": round(ms_per_step / 1e3, 4),
+        "step_dense_tflops": round(total_flops / (ms_per_step / 1e3) / 1e12, 3),
+        "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+        "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (potrf phase: n^3/3 flops over all launches)",
+                     "achieved": round(potrf_tflops, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(potrf_tflops / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None},
+        "gram_roofline": {"bound": "hbm", "achieved": round(gram_bytes / (stages["gram"] / 1e3) / 1e9, 1),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(gram_bytes / (stages["gram"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "parity": {"lml": lml, "residual_Ky_alpha_minus_y_rel": res, "mean_finite": bool(np.isfinite(mean_h).all()),
+                   "grad": [float(g) for g in grad]},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, 512)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
