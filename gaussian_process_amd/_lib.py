@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpx.so")
+LIB_PATH = os.environ.get("GPX_LIB_PATH", os.path.join(_HERE, "libgpx.so"))  # env: development override
 
 GPX_KIND = {"rbf": 0, "ard": 1}
 GPX_FULL, GPX_LOWER = 0, 1

@@ -4,60 +4,111 @@
 //
 //   D = alpha * op(A) op(B) + beta * Cin (+ diag_add on the diagonal),  row-major C/D.
 //
-// Tiling: 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 per wave =
-// 4 x 4 MFMA tiles, 128 accumulator VGPRs), BK = 16.  Each operand k-tile is staged through LDS
-// in the orientation it has in HBM (no transposition at staging time):
-//   KC operands (k contiguous in memory): LDS [128 rows][18]  -> fragment read [row][k]
-//   RC operands (row index contiguous)  : LDS [16 k][144]     -> fragment read [k][row]
-// Both paddings make the ds_read_b64 fragment reads and the ds_write_b128 staging writes
-// bank-conflict free (bank = (addr/4) % 64 per 32-lane half, MI355X_MICROARCH.md section LDS).
-// Global loads are 16 B per lane, register-staged and issued one k-tile ahead of the MFMAs.
+// Structure (MI355X-first; measured: the f64 MFMA issues once per 64 cycles per SIMD, 77.7 TFLOP/s
+// chip-wide, and only with VGPR accumulators -- AGPR accumulators run at 138 cycles):
+//   * 256-thread workgroup = 2 x 2 waves, each wave TM x TN MFMA tiles of 16 x 16
+//     (TM = TN = 4: 128 x 128 block tile, 128 accumulator VGPRs; TM = TN = 2: 64 x 64 block tile
+//     for launches too small to fill 256 CUs), BK = 16.
+//   * interior k-tiles are brought in by LDS-DMA (global_load_lds, 16 B per lane, no staging
+//     registers, no ds_write) into a double-buffered LDS image -> one barrier per k-tile, the DMA
+//     of tile t+1 flies under the MFMAs of tile t.  The image is unpadded (DMA writes lane-linear)
+//     and XOR-swizzled through the per-lane SOURCE address so the ds_read_b64 fragment reads are
+//     bank-conflict free (bank = (addr/4) % 64 per 32-lane half, MI355X_MICROARCH.md section LDS):
+//       KC operands (k contiguous in HBM): image [rows][8 slots of 16 B], slot ^= (row >> 1) & 7
+//       RC operands (row index contiguous) : image [16 k][rows/2 slots],   slot ^= (k & 1) << 3
+//   * edge tiles and tiles crossed by the diagonal of a triangular operand use guarded register
+//     loads + ds_write_b128 into the same image.
+//   * fragments for MFMA step kk+1 are read from LDS before the MFMAs of step kk are issued.
+//   * 1-D grid, remapped so that each XCD (blocks id % 8) walks 8 x 8 super-tiles: the 64 blocks
+//     resident on one XCD share 8 A panels and 8 B panels in its private L2.
 //
 // Triangular operands (a_tri / b_tri: the STORED matrix is lower triangular and starts on its
 // diagonal) restrict the k range per tile and zero-mask inside the boundary tile, so blocks that
 // lie strictly above the diagonal are never read (they may hold anything, including NaN).
 #include "gpx_internal.h"
 
+#ifndef GPX_EXP
+#define GPX_EXP 0  // development ablations only; 0 = product kernel
+#endif
+
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
-constexpr int LDK = BK + 2;    // 18 doubles: KC row stride in LDS
-constexpr int LDR = 128 + 16;  // 144 doubles: RC row stride in LDS
-constexpr int TILE_ELEMS = 128 * LDK;  // == 16 * LDR == 2304
-static_assert(128 * LDK == BK * LDR, "both LDS images have the same size");
+constexpr int BK = 16, NTHREADS = 256;
 
-// One operand's 128 x 16 k-tile: 4 x 16-byte pieces per thread.
-template <int LAY>
-struct Stage {
-  v2d v[4];
+// One operand's (R rows) x (BK) k-tile as an LDS image of 16-byte slots.
+template <int LAY, int R>
+struct Tile {
+  static constexpr int ELEMS = R * BK;
+  static constexpr int SLOTS = ELEMS / 2;
+  static constexpr int PER_THREAD = SLOTS / NTHREADS;  // 4 (R = 128) or 2 (R = 64)
+  static constexpr int SPR = R / 2;                    // slots per k row (RC)
 
-  // P: operand base; ld: leading dim; r0: first op-row (m or n) of the tile; R: extent of that
-  // index; k0: first k of the tile; K: k extent (already clipped to the tile's k range end).
-  __device__ __forceinline__ void load(const double* __restrict__ P, long ld, int r0, int R, int k0,
-                                       int K, int tri, int t) {
+  // image slot p -> coordinates (op-row r, k) of its first double
+  static __device__ __forceinline__ void decode(int p, int& r, int& k) {
+    if (LAY == GPX_LAY_KC) {
+      const int row = p >> 3;
+      r = row;
+      k = 2 * ((p & 7) ^ ((row >> 1) & 7));
+    } else {
+      const int kr = p / SPR;
+      k = kr;
+      r = 2 * ((p % SPR) ^ ((kr & 1) << 3));
+    }
+  }
+
+  // element (r, k) -> index (doubles) in the image
+  static __device__ __forceinline__ int index(int r, int k) {
+    if (LAY == GPX_LAY_KC) return r * BK + ((((k >> 1) ^ ((r >> 1) & 7))) << 1) + (k & 1);
+    return k * R + ((((r >> 1) ^ ((k & 1) << 3))) << 1) + (r & 1);
+  }
+
+  // Does the k-tile [k0, k0+BK) of the op-row tile [r0, r0+R) need the guarded loader?
+  static __device__ __forceinline__ bool needs_guard(int r0, int Rext, int k0, int K, int tri) {
+    if (r0 + R > Rext || k0 + BK > K) return true;
+    if (!tri) return false;
+    if (LAY == GPX_LAY_KC) return k0 + BK - 1 > r0;  // valid k <= r for every r >= r0
+    return r0 + R - 1 > k0;                          // valid r <= k for every k >= k0
+  }
+
+  // interior tile: LDS-DMA, 16 B per lane; wave `w` issues PER_THREAD instructions of 1 KiB
+  static __device__ __forceinline__ void dma(const double* __restrict__ P, long ld, int r0, int k0,
+                                             double* S, int t) {
+    const int lane = t & 63, w = t >> 6;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < PER_THREAD; ++q) {
+      const int pbase = (q * 4 + w) * 64;
       int r, k;
+      decode(pbase + lane, r, k);
+      const double* src = (LAY == GPX_LAY_KC) ? P + (long)(r0 + r) * ld + (k0 + k)
+                                               : P + (long)(k0 + k) * ld + (r0 + r);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(S + pbase * 2), 16, 0, 0);
+    }
+  }
+
+  // boundary tile: guarded loads (zero fill) through registers
+  static __device__ __forceinline__ void guarded(const double* __restrict__ P, long ld, int r0, int Rext,
+                                                 int k0, int K, int tri, double* S, int t) {
+    v2d v[PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < PER_THREAD; ++q) {
+      int rr, kk;
+      decode(q * NTHREADS + t, rr, kk);
+      const int r = r0 + rr, k = k0 + kk;
       bool v0, v1;
       const double* src;
-      if (LAY == GPX_LAY_KC) {
-        const int p = t & 7, rr = (t >> 3) + 32 * q;
-        r = r0 + rr;
-        k = k0 + 2 * p;
-        const bool rin = r < R;
+      if (LAY == GPX_LAY_KC) {  // pair along k; stored (row r, col k): valid k <= r
+        const bool rin = r < Rext;
         v0 = rin && (k < K) && (!tri || k <= r);
         v1 = rin && (k + 1 < K) && (!tri || k + 1 <= r);
         src = P + (long)r * ld + k;
-      } else {
-        const int pr = t & 63, kr = (t >> 6) + 4 * q;
-        r = r0 + 2 * pr;
-        k = k0 + kr;
+      } else {                  // pair along r; stored (row k, col r): valid r <= k
         const bool kin = k < K;
-        v0 = kin && (r < R) && (!tri || r <= k);
-        v1 = kin && (r + 1 < R) && (!tri || r + 1 <= k);
+        v0 = kin && (r < Rext) && (!tri || r <= k);
+        v1 = kin && (r + 1 < Rext) && (!tri || r + 1 <= k);
         src = P + (long)k * ld + r;
       }
       v2d x = {0.0, 0.0};
@@ -68,38 +119,56 @@ struct Stage {
       }
       v[q] = x;
     }
+#pragma unroll
+    for (int q = 0; q < PER_THREAD; ++q) *reinterpret_cast<v2d*>(S + 2 * (q * NTHREADS + t)) = v[q];
   }
 
-  __device__ __forceinline__ void store(double* __restrict__ S, int t) const {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int off;
-      if (LAY == GPX_LAY_KC) {
-        const int p = t & 7, rr = (t >> 3) + 32 * q;
-        off = rr * LDK + 2 * p;
-      } else {
-        const int pr = t & 63, kr = (t >> 6) + 4 * q;
-        off = kr * LDR + 2 * pr;
-      }
-      *reinterpret_cast<v2d*>(S + off) = v[q];
-    }
+  static __device__ __forceinline__ void stage(const double* __restrict__ P, long ld, int r0, int Rext,
+                                               int k0, int K, int tri, double* S, int t) {
+    if (needs_guard(r0, Rext, k0, K, tri)) guarded(P, ld, r0, Rext, k0, K, tri, S, t);
+    else dma(P, ld, r0, k0, S, t);
   }
 };
 
-template <int LAY>
-__device__ __forceinline__ double frag(const double* __restrict__ S, int tile, int kk, int i16, int g4) {
-  if (LAY == GPX_LAY_KC) return S[(tile * 16 + i16) * LDK + kk * 4 + g4];
-  return S[(kk * 4 + g4) * LDR + tile * 16 + i16];
+// Logical tile coordinates of this workgroup.  Blocks id % 8 share an XCD (round-robin dispatch,
+// MI355X_MICROARCH.md): the idx-th block of an XCD takes slot idx % 64 of super-tile
+// (idx / 64) * 8 + xcd, so the 64 workgroups resident on one XCD work on one 8 x 8 super-tile
+// (8 A panels + 8 B panels in its private L2) and super-tiles are dealt round-robin over the XCDs
+// (balanced also when the work per tile varies, as with triangular operands).
+__device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower, unsigned nsuper, int& bi,
+                                             int& bj) {
+  const unsigned bid = blockIdx.x;
+  const unsigned xcd = bid & 7, idx = bid >> 3;
+  const unsigned st = (idx >> 6) * 8 + xcd, within = idx & 63;
+  if (st >= nsuper) return false;
+  unsigned sr, sc;
+  if (lower) {
+    sr = (unsigned)((sqrt(8.0 * (double)st + 1.0) - 1.0) * 0.5);
+    while ((sr + 1) * (sr + 2) / 2 <= st) ++sr;
+    while (sr * (sr + 1) / 2 > st) --sr;
+    sc = st - sr * (sr + 1) / 2;
+  } else {
+    const unsigned stc = (tiles_n + 7) / 8;
+    sr = st / stc;
+    sc = st % stc;
+  }
+  bi = (int)(sr * 8 + (within >> 3));
+  bj = (int)(sc * 8 + (within & 7));
+  if (bi >= tiles_m || bj >= tiles_n) return false;
+  if (lower && bj > bi) return false;
+  return true;
 }
 
-template <int ALAY, int BLAY>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(const GemmDesc g) {
-  __shared__ __attribute__((aligned(16))) double smem[2 * TILE_ELEMS];
-  double* sA = smem;
-  double* sB = smem + TILE_ELEMS;
+template <int ALAY, int BLAY, int TM, int TN>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(const GemmDesc g, int tiles_m, int tiles_n,
+                                                                 unsigned nsuper) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  typedef Tile<ALAY, BM> TA;
+  typedef Tile<BLAY, BN> TB;
+  __shared__ __attribute__((aligned(16))) double smem[2 * (TA::ELEMS + TB::ELEMS)];
 
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (g.c_lower && bj > bi) return;
+  int bi, bj;
+  if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bi, bj)) return;
   const int i0 = bi * BM, j0 = bj * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
@@ -113,64 +182,117 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(const GemmDesc g)
   if (g.b_tri) {
     if (BLAY == GPX_LAY_KC) ke = min(ke, j0 + BN); else kb = max(kb, j0);
   }
+  kb &= ~(BK - 1);
 
-  v4d acc[4][4];
+  v4d acc[TM][TN];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < TN; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   if (kb < ke) {
-    Stage<ALAY> stA;
-    Stage<BLAY> stB;
-    stA.load(g.A, g.lda, i0, g.M, kb, ke, g.a_tri, t);
-    stB.load(g.B, g.ldb, j0, g.N, kb, ke, g.b_tri, t);
+    int cur = 0;
+#if GPX_EXP == 3
+    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(64);
+#endif
+#if GPX_EXP == 4
+    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
+    TA::stage(g.A, g.lda, i0, g.M, kb, ke, g.a_tri, smem, t);
+    TB::stage(g.B, g.ldb, j0, g.N, kb, ke, g.b_tri, smem + 2 * TA::ELEMS, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int k0 = kb; k0 < ke; k0 += BK) {
-      __syncthreads();  // everyone finished reading the previous tile
-      stA.store(sA, t);
-      stB.store(sB, t);
-      __syncthreads();
-      if (k0 + BK < ke) {  // next tile's loads fly under this tile's MFMAs
-        stA.load(g.A, g.lda, i0, g.M, k0 + BK, ke, g.a_tri, t);
-        stB.load(g.B, g.ldb, j0, g.N, k0 + BK, ke, g.b_tri, t);
+      const double* sA = smem + cur * TA::ELEMS;
+      const double* sB = smem + 2 * TA::ELEMS + cur * TB::ELEMS;
+      if (GPX_EXP != 1 && GPX_EXP != 2 && k0 + BK < ke) {  // next k-tile lands in the other buffer under this tile's MFMAs
+        TA::stage(g.A, g.lda, i0, g.M, k0 + BK, ke, g.a_tri, smem + (cur ^ 1) * TA::ELEMS, t);
+        TB::stage(g.B, g.ldb, j0, g.N, k0 + BK, ke, g.b_tri, smem + 2 * TA::ELEMS + (cur ^ 1) * TB::ELEMS, t);
       }
+      double fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int x = 0; x < TM; ++x) fa[0][x] = sA[TA::index((wr * TM + x) * 16 + i16, g4)];
+#pragma unroll
+      for (int y = 0; y < TN; ++y) fb[0][y] = sB[TB::index((wc * TN + y) * 16 + i16, g4)];
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
-        double a[4], b[4];
+        if (kk + 1 < BK / 4) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          a[x] = frag<ALAY>(sA, wr * 4 + x, kk, i16, g4);
-          b[x] = frag<BLAY>(sB, wc * 4 + x, kk, i16, g4);
+          for (int x = 0; x < TM; ++x)
+            fa[(kk + 1) & 1][x] = sA[TA::index((wr * TM + x) * 16 + i16, (kk + 1) * 4 + g4)];
+#pragma unroll
+          for (int y = 0; y < TN; ++y)
+            fb[(kk + 1) & 1][y] = sB[TB::index((wc * TN + y) * 16 + i16, (kk + 1) * 4 + g4)];
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < TM; ++x)
 #pragma unroll
-          for (int y = 0; y < 4; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+          for (int y = 0; y < TN; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][x], fb[kk & 1][y], acc[x][y], 0, 0, 0);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of the next tile has landed
+      if (GPX_EXP != 2) __syncthreads();
+      cur ^= 1;
     }
   }
 
-  // epilogue: C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  // epilogue: C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
+  // Cin is read with clamped (always valid) addresses, 4 * TN loads in flight per step, so the
+  // loads are branch-free and never serialise on their latency; stores are predicated.
   const double alpha = g.alpha, beta = g.beta;
+  const bool use_c = beta != 0.0;
 #pragma unroll
-  for (int x = 0; x < 4; ++x) {
+  for (int x = 0; x < TM; ++x) {
+    double cv[4][TN];
+    if (use_c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rowc = min(i0 + (wr * TM + x) * 16 + g4 + 4 * r, g.M - 1);
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+          const int colc = min(j0 + (wc * TN + y) * 16 + i16, g.N - 1);
+          cv[r][y] = g.Cin[(long)rowc * g.ldcin + colc];
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = i0 + wr * 64 + x * 16 + g4 + 4 * r;
-      if (row >= g.M) continue;
+      const int row = i0 + (wr * TM + x) * 16 + g4 + 4 * r;
 #pragma unroll
-      for (int y = 0; y < 4; ++y) {
-        const int col = j0 + wc * 64 + y * 16 + i16;
-        if (col >= g.N) continue;
-        if (g.c_lower && col > row) continue;
+      for (int y = 0; y < TN; ++y) {
+        const int col = j0 + (wc * TN + y) * 16 + i16;
         double v = alpha * acc[x][y][r];
-        if (beta != 0.0) v += beta * g.Cin[(long)row * g.ldcin + col];
+        if (use_c) v += beta * cv[r][y];
         if (row == col) v += g.diag_add;
-        g.D[(long)row * g.ldd + col] = v;
+        const bool ok = row < g.M && col < g.N && (!g.c_lower || col <= row);
+        if (ok) g.D[(long)row * g.ldd + col] = v;
       }
     }
   }
+}
+
+template <int TM, int TN>
+int launch_cfg(hipStream_t s, const GemmDesc& g) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+  unsigned nsuper;
+  if (g.c_lower) {
+    const unsigned S = (unsigned)((max(tm, tn) + 7) / 8);
+    nsuper = S * (S + 1) / 2;
+  } else {
+    nsuper = (unsigned)((tm + 7) / 8) * (unsigned)((tn + 7) / 8);
+  }
+  dim3 grid(((nsuper + 7) / 8) * 8 * 64), block(NTHREADS);
+  if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
+    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
+  else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
+    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
+  else if (g.a_lay == GPX_LAY_RC && g.b_lay == GPX_LAY_RC)
+    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
+  else
+    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
+  GPX_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace
@@ -185,16 +307,9 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   GPX_REQUIRE(g.lda >= (g.a_lay == GPX_LAY_KC ? g.K : g.M), "gemm: lda too small");
   GPX_REQUIRE(g.ldb >= (g.b_lay == GPX_LAY_KC ? g.K : g.N), "gemm: ldb too small");
   GPX_REQUIRE(g.ldd >= g.N, "gemm: ldd too small");
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
-  dim3 block(NTHREADS);
-  if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
-    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC>), grid, block, 0, s, g);
-  else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
-    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC>), grid, block, 0, s, g);
-  else if (g.a_lay == GPX_LAY_RC && g.b_lay == GPX_LAY_RC)
-    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC>), grid, block, 0, s, g);
-  else
-    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC>), grid, block, 0, s, g);
-  GPX_HIP(hipGetLastError());
-  return 0;
+  // 128 x 128 tiles unless that leaves most of the 256 CUs (2 workgroups each) idle.  In-place
+  // launches (D aliases an operand) rely on one workgroup owning a whole operand panel: 128 only.
+  const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.c_lower ? 2 : 1);
+  if (g.inplace || big_tiles >= 384) return launch_cfg<4, 4>(s, g);
+  return launch_cfg<2, 2>(s, g);
 }

@@ -56,6 +56,7 @@ struct GemmDesc {
   double alpha, beta;
   int c_lower;       // write only row >= col (D starts on the diagonal)
   double diag_add;   // added to D[i][i]
+  int inplace;       // D aliases A or B (leaf solves): one workgroup must own the whole panel
 };
 
 int gpx_gemm_launch(hipStream_t s, const GemmDesc& g);
