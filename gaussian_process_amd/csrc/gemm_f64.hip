@@ -27,9 +27,6 @@
 // lie strictly above the diagonal are never read (they may hold anything, including NaN).
 #include "gpx_internal.h"
 
-#ifndef GPX_EXP
-#define GPX_EXP 0  // development ablations only; 0 = product kernel
-#endif
 
 namespace {
 
@@ -37,6 +34,21 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16, NTHREADS = 256;
+
+// LDS-DMA of 16 bytes per lane: global `src` (per lane) -> LDS `dst_wave` + lane * 16 (wave-uniform base).
+__device__ __forceinline__ void glds16(const char* src, double* dst_wave) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst_wave, 16, 0, 0);
+}
+
+// Tell the compiler a pointer is wave-uniform (kept in SGPRs), so that `p + lane_offset` becomes the
+// saddr + 32-bit voffset form of the load instead of 64-bit VALU adds.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
 
 // One operand's (R rows) x (BK) k-tile as an LDS image of 16-byte slots.
 template <int LAY, int R>
@@ -65,28 +77,29 @@ struct Tile {
     return k * R + ((((r >> 1) ^ ((k & 1) << 3))) << 1) + (r & 1);
   }
 
+  // Fragment addressing split into a per-lane base (computed once) and compile-time offsets.
+  // For tile T (16 op-rows) and MFMA k-step kk the element read by lane (i16, g4) is
+  // index(T*16 + i16, 4*kk + g4) == frag_base(frag_sel(T, kk), i16, g4) + frag_off(T, kk).
+  static constexpr int NBASE = (LAY == GPX_LAY_KC) ? BK / 4 : 2;
+  static __device__ __forceinline__ int frag_base(int sel, int i16, int g4) {
+    if (LAY == GPX_LAY_KC) {  // sel = kk
+      const int c = (g4 >> 1) ^ ((i16 >> 1) & 7);
+      return i16 * BK + (((2 * sel) ^ c) << 1) + (g4 & 1);
+    }
+    const int b = g4 & 1;     // sel = T & 1: T ^ b == T + b (T even), T - b (T odd)
+    return g4 * R + i16 + (sel ? -16 * b : 16 * b);
+  }
+  static constexpr __device__ __forceinline__ int frag_sel(int T, int kk) { return LAY == GPX_LAY_KC ? kk : (T & 1); }
+  static constexpr __device__ __forceinline__ int frag_off(int T, int kk) {
+    return LAY == GPX_LAY_KC ? T * 16 * BK : kk * 4 * R + 16 * T;
+  }
+
   // Does the k-tile [k0, k0+BK) of the op-row tile [r0, r0+R) need the guarded loader?
   static __device__ __forceinline__ bool needs_guard(int r0, int Rext, int k0, int K, int tri) {
     if (r0 + R > Rext || k0 + BK > K) return true;
     if (!tri) return false;
     if (LAY == GPX_LAY_KC) return k0 + BK - 1 > r0;  // valid k <= r for every r >= r0
     return r0 + R - 1 > k0;                          // valid r <= k for every k >= k0
-  }
-
-  // interior tile: LDS-DMA, 16 B per lane; wave `w` issues PER_THREAD instructions of 1 KiB
-  static __device__ __forceinline__ void dma(const double* __restrict__ P, long ld, int r0, int k0,
-                                             double* S, int t) {
-    const int lane = t & 63, w = t >> 6;
-#pragma unroll
-    for (int q = 0; q < PER_THREAD; ++q) {
-      const int pbase = (q * 4 + w) * 64;
-      int r, k;
-      decode(pbase + lane, r, k);
-      const double* src = (LAY == GPX_LAY_KC) ? P + (long)(r0 + r) * ld + (k0 + k)
-                                               : P + (long)(k0 + k) * ld + (r0 + r);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(S + pbase * 2), 16, 0, 0);
-    }
   }
 
   // boundary tile: guarded loads (zero fill) through registers
@@ -123,11 +136,6 @@ struct Tile {
     for (int q = 0; q < PER_THREAD; ++q) *reinterpret_cast<v2d*>(S + 2 * (q * NTHREADS + t)) = v[q];
   }
 
-  static __device__ __forceinline__ void stage(const double* __restrict__ P, long ld, int r0, int Rext,
-                                               int k0, int K, int tri, double* S, int t) {
-    if (needs_guard(r0, Rext, k0, K, tri)) guarded(P, ld, r0, Rext, k0, K, tri, S, t);
-    else dma(P, ld, r0, k0, S, t);
-  }
 };
 
 // Logical tile coordinates of this workgroup.  Blocks id % 8 share an XCD (round-robin dispatch,
@@ -160,7 +168,7 @@ __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower
 }
 
 template <int ALAY, int BLAY, int TM, int TN>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(const GemmDesc g, int tiles_m, int tiles_n,
+__global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 4))) void gemm_f64_kernel(const GemmDesc g, int tiles_m, int tiles_n,
                                                                  unsigned nsuper) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   typedef Tile<ALAY, BM> TA;
@@ -191,48 +199,113 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(const GemmDesc g,
     for (int b = 0; b < TN; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   if (kb < ke) {
-    int cur = 0;
-#if GPX_EXP == 3
-    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(64);
-#endif
-#if GPX_EXP == 4
-    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(1);
-#endif
-    TA::stage(g.A, g.lda, i0, g.M, kb, ke, g.a_tri, smem, t);
-    TB::stage(g.B, g.ldb, j0, g.N, kb, ke, g.b_tri, smem + 2 * TA::ELEMS, t);
+    // Everything the k loop needs per lane is computed here, once: the f64 MFMA shares its issue
+    // bandwidth with ordinary VALU instructions (measured: ~6 cycles of MFMA time lost per VALU
+    // instruction even with two waves per SIMD), so the steady-state loop is MFMA + LDS reads +
+    // LDS-DMA + scalar bookkeeping only.
+    const int w = __builtin_amdgcn_readfirstlane(wid);  // wave id, provably uniform
+    unsigned offA[TA::PER_THREAD], offB[TB::PER_THREAD];  // per-lane byte offsets of the DMA pieces
+#pragma unroll
+    for (int q = 0; q < TA::PER_THREAD; ++q) {
+      int r, k;
+      TA::decode((q * 4 + w) * 64 + lane, r, k);
+      offA[q] = (ALAY == GPX_LAY_KC ? (unsigned)r * (unsigned)g.lda + k : (unsigned)k * (unsigned)g.lda + r) * 8u;
+    }
+#pragma unroll
+    for (int q = 0; q < TB::PER_THREAD; ++q) {
+      int r, k;
+      TB::decode((q * 4 + w) * 64 + lane, r, k);
+      offB[q] = (BLAY == GPX_LAY_KC ? (unsigned)r * (unsigned)g.ldb + k : (unsigned)k * (unsigned)g.ldb + r) * 8u;
+    }
+    // wave-uniform byte address of the k-tile being staged, and its advance per k-tile
+    const char* gA = reinterpret_cast<const char*>(ALAY == GPX_LAY_KC ? g.A + (long)i0 * g.lda + kb
+                                                                      : g.A + (long)kb * g.lda + i0);
+    const char* gB = reinterpret_cast<const char*>(BLAY == GPX_LAY_KC ? g.B + (long)j0 * g.ldb + kb
+                                                                      : g.B + (long)kb * g.ldb + j0);
+    const long stepA = (ALAY == GPX_LAY_KC ? (long)BK : (long)BK * g.lda) * 8;
+    const long stepB = (BLAY == GPX_LAY_KC ? (long)BK : (long)BK * g.ldb) * 8;
+    double* const smA = smem;
+    double* const smB = smem + 2 * TA::ELEMS;
+    // per-lane fragment pointers; the tile / k-step / buffer parts are immediates
+    const double* pa[TA::NBASE];
+    const double* pb[TB::NBASE];
+#pragma unroll
+    for (int i = 0; i < TA::NBASE; ++i) pa[i] = smA + TA::frag_base(i, i16, g4);
+#pragma unroll
+    for (int i = 0; i < TB::NBASE; ++i) pb[i] = smB + TB::frag_base(i, i16, g4);
+
+    auto stage_a = [&](int k0, int buf) {
+      if (TA::needs_guard(i0, g.M, k0, ke, g.a_tri)) {
+        TA::guarded(g.A, g.lda, i0, g.M, k0, ke, g.a_tri, smA + buf * TA::ELEMS, t);
+      } else {
+        const char* sa = uniform_ptr(gA);
+#pragma unroll
+        for (int q = 0; q < TA::PER_THREAD; ++q) {
+          unsigned o = offA[q];
+          asm volatile("" : "+v"(o));  // keep the offset 32-bit: saddr + voffset addressing, no 64-bit VALU add
+          glds16(sa + o, smA + buf * TA::ELEMS + (q * 4 + w) * 128);
+        }
+      }
+    };
+    auto stage_b = [&](int k0, int buf) {
+      if (TB::needs_guard(j0, g.N, k0, ke, g.b_tri)) {
+        TB::guarded(g.B, g.ldb, j0, g.N, k0, ke, g.b_tri, smB + buf * TB::ELEMS, t);
+      } else {
+        const char* sb = uniform_ptr(gB);
+#pragma unroll
+        for (int q = 0; q < TB::PER_THREAD; ++q) {
+          unsigned o = offB[q];
+          asm volatile("" : "+v"(o));
+          glds16(sb + o, smB + buf * TB::ELEMS + (q * 4 + w) * 128);
+        }
+      }
+    };
+
+    stage_a(kb, 0);
+    stage_b(kb, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int k0 = kb; k0 < ke; k0 += BK) {
-      const double* sA = smem + cur * TA::ELEMS;
-      const double* sB = smem + 2 * TA::ELEMS + cur * TB::ELEMS;
-      if (GPX_EXP != 1 && GPX_EXP != 2 && k0 + BK < ke) {  // next k-tile lands in the other buffer under this tile's MFMAs
-        TA::stage(g.A, g.lda, i0, g.M, k0 + BK, ke, g.a_tri, smem + (cur ^ 1) * TA::ELEMS, t);
-        TB::stage(g.B, g.ldb, j0, g.N, k0 + BK, ke, g.b_tri, smem + 2 * TA::ELEMS + (cur ^ 1) * TB::ELEMS, t);
-      }
-      double fa[2][TM], fb[2][TN];
+    for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
 #pragma unroll
-      for (int x = 0; x < TM; ++x) fa[0][x] = sA[TA::index((wr * TM + x) * 16 + i16, g4)];
-#pragma unroll
-      for (int y = 0; y < TN; ++y) fb[0][y] = sB[TB::index((wc * TN + y) * 16 + i16, g4)];
-#pragma unroll
-      for (int kk = 0; kk < BK / 4; ++kk) {
-        if (kk + 1 < BK / 4) {
-#pragma unroll
-          for (int x = 0; x < TM; ++x)
-            fa[(kk + 1) & 1][x] = sA[TA::index((wr * TM + x) * 16 + i16, (kk + 1) * 4 + g4)];
-#pragma unroll
-          for (int y = 0; y < TN; ++y)
-            fb[(kk + 1) & 1][y] = sB[TB::index((wc * TN + y) * 16 + i16, (kk + 1) * 4 + g4)];
-        }
+      for (int cur = 0; cur < 2; ++cur) {  // unrolled: the LDS buffer index is a compile-time constant
+        const int kt = k0 + cur * BK;
+        if (kt >= ke) break;
+        gA += stepA;
+        gB += stepB;
+        double fa[2][TM], fb[2][TN];
+        // first fragments of this tile: start the LDS reads, then issue the DMA under their latency
 #pragma unroll
         for (int x = 0; x < TM; ++x)
+          fa[0][x] = pa[TA::frag_sel(wr * TM + x, 0)][cur * TA::ELEMS + TA::frag_off(wr * TM + x, 0)];
 #pragma unroll
-          for (int y = 0; y < TN; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][x], fb[kk & 1][y], acc[x][y], 0, 0, 0);
+        for (int y = 0; y < TN; ++y)
+          fb[0][y] = pb[TB::frag_sel(wc * TN + y, 0)][cur * TB::ELEMS + TB::frag_off(wc * TN + y, 0)];
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + BK < ke) {  // next k-tile lands in the other buffer under this tile's MFMAs
+          stage_a(kt + BK, cur ^ 1);
+          stage_b(kt + BK, cur ^ 1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+          if (kk + 1 < BK / 4) {
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+              fa[(kk + 1) & 1][x] =
+                  pa[TA::frag_sel(wr * TM + x, kk + 1)][cur * TA::ELEMS + TA::frag_off(wr * TM + x, kk + 1)];
+#pragma unroll
+            for (int y = 0; y < TN; ++y)
+              fb[(kk + 1) & 1][y] =
+                  pb[TB::frag_sel(wc * TN + y, kk + 1)][cur * TB::ELEMS + TB::frag_off(wc * TN + y, kk + 1)];
+          }
+#pragma unroll
+          for (int x = 0; x < TM; ++x)
+#pragma unroll
+            for (int y = 0; y < TN; ++y)
+              acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][x], fb[kk & 1][y], acc[x][y], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of the next tile has landed
+        __syncthreads();
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of the next tile has landed
-      if (GPX_EXP != 2) __syncthreads();
-      cur ^= 1;
     }
   }
 
@@ -307,6 +380,7 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   GPX_REQUIRE(g.lda >= (g.a_lay == GPX_LAY_KC ? g.K : g.M), "gemm: lda too small");
   GPX_REQUIRE(g.ldb >= (g.b_lay == GPX_LAY_KC ? g.K : g.N), "gemm: ldb too small");
   GPX_REQUIRE(g.ldd >= g.N, "gemm: ldd too small");
+  GPX_REQUIRE(g.lda < (1L << 21) && g.ldb < (1L << 21), "gemm: leading dimension >= 2^21 (32-bit lane offsets)");
   // 128 x 128 tiles unless that leaves most of the 256 CUs (2 workgroups each) idle.  In-place
   // launches (D aliases an operand) rely on one workgroup owning a whole operand panel: 128 only.
   const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.c_lower ? 2 : 1);
