@@ -29,8 +29,8 @@ __global__ __launch_bounds__(256, WPS) void mfma_loop(double* out, int iters, un
 }
 
 template <int NACC, int WPS>
-void run(int waves_per_simd, int iters) {
-  int blocks = 256 * waves_per_simd;  // 256 threads = 4 waves = 1 wave per SIMD per block
+void run(int waves_per_simd, int iters, int blocks_override = 0) {
+  int blocks = blocks_override ? blocks_override : 256 * waves_per_simd;  // 256 threads = 4 waves = 1 wave per SIMD per block
   double* out; unsigned long long *cyc, *rt;
   hipMalloc(&out, sizeof(double) * blocks * 256);
   hipMalloc(&cyc, sizeof(unsigned long long) * blocks);
@@ -56,6 +56,8 @@ void run(int waves_per_simd, int iters) {
 }
 
 int main() {
+  run<4, 2>(1, 3000, 1);
+  run<4, 2>(1, 300, 1);
   run<16, 1>(1, 40000);
   run<16, 2>(1, 40000);
   run<16, 2>(2, 40000);
