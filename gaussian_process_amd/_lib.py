@@ -29,6 +29,8 @@ SIGNATURES = {
     "gpx_gram": (_i, [C.c_void_p, _i, _dp, _i, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _i, _i]),
     "gpx_gram_dtheta": (_i, [C.c_void_p, _i, _dp, _i, _i, _dp, _i, _i, _i, _d, _hp, _dp, _dp, _dp, _i, _sz]),
     "gpx_potrf": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
+    "gpx_potrf_async": (_i, [C.c_void_p, _i, _dp, _i, _dp, _dp, _i]),
+    "gpx_trsm_right": (_i, [C.c_void_p, _i, _i, _dp, _i, _dp, _dp, _i]),
     "gpx_diag_inv": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
     "gpx_trsm": (_i, [C.c_void_p, _i, _i, _i, _dp, _i, _dp, _dp, _i]),
     "gpx_logdet": (_i, [C.c_void_p, _i, _dp, _i, _hp]),

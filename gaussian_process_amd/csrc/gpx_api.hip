@@ -299,6 +299,27 @@ int gpx_potrf(gpx_handle* h, int n, double* A, int lda, double* dinv) {
   return info;
 }
 
+int gpx_potrf_async(gpx_handle* h, int n, double* A, int lda, double* dinv, int* info_dev, int info_offset) {
+  GPX_REQUIRE(h != nullptr, "null handle");
+  GPX_REQUIRE(n >= 0, "potrf_async: negative n");
+  if (n == 0) return 0;
+  GPX_TRY(check_mat("potrf_async: A", A, lda, n));
+  GPX_REQUIRE(dinv != nullptr && gpx_aligned16(dinv) && info_dev != nullptr, "potrf_async: dinv/info null or misaligned");
+  DeviceGuard dg(h->device);
+  return potrf_rec(h->stream, n, A, lda, dinv, info_dev, info_offset);
+}
+
+int gpx_trsm_right(gpx_handle* h, int m, int n, const double* L, int ldl, const double* dinv, double* X,
+                   int ldx) {
+  GPX_REQUIRE(h != nullptr, "null handle");
+  if (m <= 0 || n <= 0) return 0;
+  GPX_TRY(check_mat("trsm_right: L", L, ldl, n));
+  GPX_TRY(check_mat("trsm_right: X", X, ldx, n));
+  GPX_REQUIRE(dinv != nullptr && gpx_aligned16(dinv), "trsm_right: dinv null or misaligned");
+  DeviceGuard dg(h->device);
+  return trsm_rlt(h->stream, m, n, L, ldl, dinv, X, ldx);
+}
+
 int gpx_diag_inv(gpx_handle* h, int n, const double* L, int ldl, double* dinv) {
   GPX_REQUIRE(h != nullptr, "null handle");
   if (n <= 0) return 0;

@@ -1,0 +1,266 @@
+"""Multi-GPU exact GP regression: block-column-cyclic Cholesky with panel broadcasts over
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+One process per GPU.  The reference has no distributed code at all; what is distributed here is
+the arithmetic of regression.py:31-55 (Gram, ``cholesky``, the triangular solves, LML, predictive
+mean / covariance), with the same kernels as the single-GPU path (libgpx) doing all local work.
+
+Layout and algorithm (realised 1-D for round 1):
+  * every rank holds an n x n row-major buffer; block column j (width ``block``, rows >= j*block)
+    is OWNED by rank j % P, which builds it (Gram, no communication: X is replicated) and applies
+    every trailing update to it;
+  * step k: the owner factors the diagonal block (``gpx_potrf_async``), solves the panel below it
+    (``gpx_trsm_right``), packs panel k (+ its 128x128 diagonal-block inverses) into a contiguous
+    staging buffer and broadcasts it; every rank then updates its own block columns j > k with
+    ``A[j0:, j] -= P[j0:, :] P[j0:j0+b, :]^T`` (one MFMA GEMM each) and files the panel into its
+    buffer, so after the last step EVERY rank holds the complete factor L;
+  * look-ahead: the owner of panel k+1 updates and factors it first and posts its broadcast
+    (async, RCCL's own stream) before the bulk updates of step k are enqueued, so the transfer
+    and the panel factorisation hide under the other ranks' GEMMs;
+  * solves after the factorisation are split by right-hand-side column: rank r computes
+    ``V[:, cols_r] = L^-1 k*(:, cols_r)``; V is all-gathered for the ``V^T V`` block rows.
+Communication per step: one broadcast of (n - k*block) x block doubles (the whole lower triangle
+once per rank over the factorisation, 17 GB at n = 65536) -- no other data-path collective.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def owner_of(block_index, world):
+    return block_index % world
+
+
+class GpuOps:
+    """Local kernels through the C ABI on torch device tensors (views carry pointer + stride)."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.lib = rt.lib
+        self.h = rt.h
+        self.torch = rt.torch
+        self.device = rt.dev
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def empty(self, *shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    def zeros(self, *shape, dtype=None):
+        return self.torch.zeros(shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    def gram(self, kind, sigma, beta, Xr, Xc, out, diag_add):
+        barr, bp = _lib.host_doubles(beta)
+        _lib.check(self.lib.gpx_gram(self.h, kind, self._p(Xr), Xr.shape[0], Xr.stride(0), self._p(Xc),
+                                     Xc.shape[0], Xc.stride(0), Xr.shape[1], float(sigma), bp, float(diag_add),
+                                     self._p(out), out.stride(0), _lib.GPX_FULL), "gpx_gram")
+
+    def potrf_async(self, Akk, dinv, info, info_offset):
+        _lib.check(self.lib.gpx_potrf_async(self.h, Akk.shape[0], self._p(Akk), Akk.stride(0), self._p(dinv),
+                                            self._p(info), int(info_offset)), "gpx_potrf_async")
+
+    def trsm_right(self, Xp, Lkk, dinv):
+        _lib.check(self.lib.gpx_trsm_right(self.h, Xp.shape[0], Xp.shape[1], self._p(Lkk), Lkk.stride(0),
+                                           self._p(dinv), self._p(Xp), Xp.stride(0)), "gpx_trsm_right")
+
+    def gemm(self, ta, tb, M, N, K, alpha, A, B, beta, Cm):
+        _lib.check(self.lib.gpx_gemm(self.h, ta, tb, M, N, K, float(alpha), self._p(A), A.stride(0), self._p(B),
+                                     B.stride(0), float(beta), self._p(Cm), Cm.stride(0)), "gpx_gemm")
+
+    def trsm_left(self, trans, L, dinv, B):
+        _lib.check(self.lib.gpx_trsm(self.h, trans, L.shape[0], B.shape[1], self._p(L), L.stride(0),
+                                     self._p(dinv), self._p(B), B.stride(0)), "gpx_trsm")
+
+    def logdet(self, L):
+        out = C.c_double()
+        _lib.check(self.lib.gpx_logdet(self.h, L.shape[0], self._p(L), L.stride(0), C.byref(out)), "gpx_logdet")
+        return out.value
+
+    def dot(self, n, x, y):
+        out = C.c_double()
+        _lib.check(self.lib.gpx_dot(self.h, n, self._p(x), self._p(y), C.byref(out)), "gpx_dot")
+        return out.value
+
+    def gemv_t(self, A, x, y):
+        _lib.check(self.lib.gpx_gemv(self.h, 1, A.shape[0], A.shape[1], self._p(A), A.stride(0), self._p(x),
+                                     self._p(y)), "gpx_gemv")
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class DistributedGP:
+    """Exact GP regression over the ranks of a torch.distributed process group."""
+
+    def __init__(self, ops, dist, rank, world, block=2048, group=None):
+        assert block % _lib.GPX_NB == 0, "block must be a multiple of 128"
+        self.ops, self.dist, self.rank, self.world, self.block, self.group = ops, dist, rank, world, block, group
+        self.torch = ops.torch
+        self.n = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _blocks(self):
+        b = self.block
+        return [(k, k * b, min(b, self.n - k * b)) for k in range((self.n + b - 1) // b)]
+
+    def _dinv_slice(self, k0, kb):
+        nb = _lib.GPX_NB
+        lo = (k0 // nb) * nb * nb
+        return self.dinv[lo: lo + ((kb + nb - 1) // nb) * nb * nb]
+
+    def _bcast(self, t, src, async_op=False):
+        return self.dist.broadcast(t, src=src, group=self.group, async_op=async_op)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X, y, kind, sigma, beta, noise):
+        """Gram + distributed Cholesky + alpha + LML.  X (n, d), y (n,) host arrays, identical on
+        every rank.  Returns (lml, info); the factor stays resident for predict()."""
+        ops, t = self.ops, self.torch
+        n, d = X.shape
+        self.n, self.d = n, d
+        self.kind, self.sigma, self.beta, self.noise = _lib.GPX_KIND[kind], float(sigma), np.asarray(beta, float), float(noise)
+        ld = max(32, ((n + 31) // 32) * 32)
+        self.A = ops.empty(n, ld)
+        self.X = ops.zeros(n, max(32, ((d + 31) // 32) * 32))
+        self.X[:, :d].copy_(t.from_numpy(np.ascontiguousarray(X, dtype=np.float64)))
+        self.y = ops.empty(max(n, 2))
+        self.y[:n].copy_(t.from_numpy(np.ascontiguousarray(y, dtype=np.float64)))
+        self.dinv = ops.empty(max(((n + 127) // 128) * 128 * 128, 2))
+        self.info = ops.zeros(64, dtype=t.int32)
+        self.build_gram()
+        self.potrf()
+        return self.solve_lml()
+
+    def build_gram(self):
+        """Each rank fills only the block columns it owns (rows from the diagonal block down)."""
+        for k, k0, kb in self._blocks():
+            if owner_of(k, self.world) != self.rank:
+                continue
+            Xv = self.X[:, : self.d]
+            self.ops.gram(self.kind, self.sigma, self.beta, Xv[k0:], Xv[k0:k0 + kb],
+                          self.A[k0:self.n, k0:k0 + kb], self.noise)
+
+    def _factor_panel(self, k, k0, kb, stg):
+        """Owner side of step k: potrf of the diagonal block, TRSM of the rows below, pack."""
+        n = self.n
+        Akk = self.A[k0:k0 + kb, k0:k0 + kb]
+        dk = self._dinv_slice(k0, kb)
+        self.ops.potrf_async(Akk, dk, self.info, k0)
+        if k0 + kb < n:
+            self.ops.trsm_right(self.A[k0 + kb:n, k0:k0 + kb], Akk, dk)
+        nk = n - k0
+        stg[: nk * kb].view(nk, kb).copy_(self.A[k0:n, k0:k0 + kb])
+        stg[nk * kb: nk * kb + dk.numel()].copy_(dk)
+
+    def _panel_len(self, k0, kb):
+        return (self.n - k0) * kb + self._dinv_slice(k0, kb).numel()
+
+    def _update_column(self, j0, jb, Pk, k0):
+        """A[j0:, j0:j0+jb] -= P[j0-k0:, :] P[j0-k0 : j0-k0+jb, :]^T  (panel k given as Pk)."""
+        n = self.n
+        rows = Pk[j0 - k0:]
+        self.ops.gemm(0, 1, n - j0, jb, Pk.shape[1], -1.0, rows, Pk[j0 - k0: j0 - k0 + jb], 1.0,
+                      self.A[j0:n, j0:j0 + jb])
+
+    def potrf(self):
+        ops, t, n, b = self.ops, self.torch, self.n, self.block
+        blocks = self._blocks()
+        cap = n * b + ((b + 127) // 128) * 128 * 128
+        stg = [ops.empty(cap), ops.empty(cap)]
+        k, k0, kb = blocks[0]
+        if owner_of(0, self.world) == self.rank:
+            self._factor_panel(0, k0, kb, stg[0])
+        work = self._bcast(stg[0][: self._panel_len(k0, kb)], owner_of(0, self.world), async_op=True)
+        for k, k0, kb in blocks:
+            work.wait()
+            cur = stg[k % 2]
+            nk = n - k0
+            Pk = cur[: nk * kb].view(nk, kb)
+            mine = owner_of(k, self.world) == self.rank
+            done_ahead = -1
+            if k + 1 < len(blocks):
+                k1, k10, k1b = blocks[k + 1]
+                o1 = owner_of(k1, self.world)
+                if o1 == self.rank:  # look-ahead: bring panel k+1 up to date, factor it, send it
+                    self._update_column(k10, k1b, Pk, k0)
+                    self._factor_panel(k1, k10, k1b, stg[k1 % 2])
+                    done_ahead = k1
+                work = self._bcast(stg[k1 % 2][: self._panel_len(k10, k1b)], o1, async_op=True)
+            if not mine:  # file panel k (and its diagonal inverses) so every rank ends with all of L
+                self.A[k0:n, k0:k0 + kb].copy_(Pk)
+                dk = self._dinv_slice(k0, kb)
+                dk.copy_(cur[nk * kb: nk * kb + dk.numel()])
+            for j, j0, jb in blocks[k + 1:]:
+                if owner_of(j, self.world) == self.rank and j != done_ahead:
+                    self._update_column(j0, jb, Pk, k0)
+        # LAPACK info: smallest failing leading minor over all ranks (0 = success)
+        big = 2 ** 30
+        loc = int(self.info[0].item())
+        val = t.tensor([loc if loc > 0 else big], dtype=t.int64, device=self.A.device)
+        self.dist.all_reduce(val, op=self.dist.ReduceOp.MIN, group=self.group)
+        self.info_value = 0 if int(val.item()) >= big else int(val.item())
+        return self.info_value
+
+    def solve_lml(self):
+        """a = L^-1 y, alpha = L^-T a, LML (regression.py:50-55, 61); replicated on every rank."""
+        ops, t, n = self.ops, self.torch, self.n
+        _lib.check(self.info_value, "distributed potrf")
+        L = self.A[:n, :n]
+        rhs = ops.zeros(n, 2)
+        rhs[:, 0].copy_(self.y[:n])
+        ops.trsm_left(0, L, self.dinv, rhs[:, :1])
+        self.a = rhs[:, 0].clone()
+        ops.trsm_left(1, L, self.dinv, rhs[:, :1])
+        self.alpha = rhs[:, 0].clone()
+        aa = ops.dot(n, self.a, self.a)
+        self.lml = -0.5 * aa - ops.logdet(L) - 0.5 * n * np.log(2.0 * np.pi)
+        return self.lml
+
+    # ------------------------------------------------------------------ predict
+    def predict(self, Xs):
+        """regression.py:31-44 with the m test points split over the ranks.  Returns (mean, cov) as
+        host arrays on every rank."""
+        ops, t, n, d, P, r = self.ops, self.torch, self.n, self.d, self.world, self.rank
+        m = Xs.shape[0]
+        mc = (m + P - 1) // P
+        mc = max(2, mc + (mc & 1))                      # even chunk width (16-byte rows)
+        c0, c1 = min(m, r * mc), min(m, (r + 1) * mc)
+        Xs_d = ops.zeros(max(m, 1), self.X.shape[1])
+        Xs_d[:m, :d].copy_(t.from_numpy(np.ascontiguousarray(Xs, dtype=np.float64)))
+        L = self.A[:n, :n]
+        V = ops.zeros(n, mc)
+        if c1 > c0:
+            ops.gram(self.kind, self.sigma, self.beta, self.X[:, :d], Xs_d[c0:c1, :d], V[:, : c1 - c0], 0.0)
+            ops.trsm_left(0, L, self.dinv, V[:, : c1 - c0])
+        mean_loc = ops.zeros(mc)
+        ops.gemv_t(V, self.a, mean_loc)
+        means = [ops.empty(mc) for _ in range(P)]
+        self.dist.all_gather(means, mean_loc, group=self.group)
+        mean = t.cat([means[s][: max(0, min(m, (s + 1) * mc) - min(m, s * mc))] for s in range(P)])
+        Vs = [ops.empty(n, mc) for _ in range(P)]
+        self.dist.all_gather(Vs, V, group=self.group)
+        mpad = P * mc
+        cov_loc = ops.zeros(mc, mpad + (mpad & 1))
+        if c1 > c0:
+            for s in range(P):
+                s0, s1 = min(m, s * mc), min(m, (s + 1) * mc)
+                if s1 <= s0:
+                    continue
+                blk = cov_loc[: c1 - c0, s * mc: s * mc + (s1 - s0)]
+                ops.gram(self.kind, self.sigma, self.beta, Xs_d[c0:c1, :d], Xs_d[s0:s1, :d], blk,
+                         self.noise if s == r else 0.0)
+                ops.gemm(1, 0, c1 - c0, s1 - s0, n, -1.0, V, Vs[s], 1.0, blk)
+        covs = [ops.empty(mc, cov_loc.shape[1]) for _ in range(P)]
+        self.dist.all_gather(covs, cov_loc, group=self.group)
+        rows = []
+        for s in range(P):
+            s0, s1 = min(m, s * mc), min(m, (s + 1) * mc)
+            if s1 > s0:
+                rows.append(t.cat([covs[s][: s1 - s0, q * mc: q * mc + max(0, min(m, (q + 1) * mc) - min(m, q * mc))]
+                                   for q in range(P)], dim=1))
+        cov = t.cat(rows, dim=0)
+        return mean.cpu().numpy(), cov.cpu().numpy()

@@ -83,6 +83,14 @@ int gpx_gram_dtheta(gpx_handle* h, int kind, const double* X1, int n1, int ldx1,
  * Replaces scipy.linalg.cholesky(lower=True) at regression.py:36,49 and np.linalg.cholesky at
  * expectation_propagation.py:62,91.  Returns LAPACK info (>0: leading minor not PD). */
 int gpx_potrf(gpx_handle* h, int n, double* A, int lda, double* dinv);
+/* Same factorisation without the host synchronisation: LAPACK info is left in info_dev (a device
+ * int the caller zeroes first; only the first failure is recorded).  For callers that pipeline
+ * panels (the multi-GPU block-column Cholesky). */
+int gpx_potrf_async(gpx_handle* h, int n, double* A, int lda, double* dinv, int* info_dev, int info_offset);
+/* X (m x n, row-major) <- X L^-T for the n x n lower factor L: the panel solve
+ * A21 L11^-T inside a blocked Cholesky (dtrsm 'R','L','T' inside dpotrf, regression.py:36,49). */
+int gpx_trsm_right(gpx_handle* h, int m, int n, const double* L, int ldl, const double* dinv, double* X,
+                   int ldx);
 /* Recompute dinv for a factor L that did not come from gpx_potrf. */
 int gpx_diag_inv(gpx_handle* h, int n, const double* L, int ldl, double* dinv);
 /* B <- L^-1 B (trans = 0) or L^-T B (trans = 1); B is n x nrhs row-major (nrhs may be 1).

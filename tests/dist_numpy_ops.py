@@ -1,0 +1,100 @@
+"""Test double for gaussian_process_amd.distributed.GpuOps: the same per-rank primitive
+interface on CPU torch tensors with NumPy/SciPy arithmetic.  TEST INFRASTRUCTURE ONLY -- it lets
+the world_size>1 control flow (ownership, look-ahead, staging, broadcasts, info reduction, the
+RHS-split predict) run under gloo on a machine without a GPU.  Never imported by the package."""
+import numpy as np
+import scipy.linalg as sla
+import torch
+
+from oracle import gp_oracle as orc
+
+KIND_NAME = {0: "rbf", 1: "ard"}
+NB = 128
+
+
+class NumpyOps:
+    torch = torch
+    device = torch.device("cpu")
+
+    def empty(self, *shape, dtype=None):
+        # poison instead of "uninitialised": reads of never-written memory show up as NaN
+        t = torch.empty(shape, dtype=dtype or torch.float64)
+        if t.dtype == torch.float64:
+            t.fill_(float("nan"))
+        return t
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(shape, dtype=dtype or torch.float64)
+
+    def gram(self, kind, sigma, beta, Xr, Xc, out, diag_add):
+        K = orc.cov(KIND_NAME[kind], Xr.numpy().copy(), Xc.numpy().copy(), sigma, beta)[0]
+        k = min(K.shape)
+        K[np.arange(k), np.arange(k)] += diag_add
+        out.numpy()[...] = K
+
+    def potrf_async(self, Akk, dinv, info, info_offset):
+        a = Akk.numpy()
+        n = a.shape[0]
+        sym = np.tril(a) + np.tril(a, -1).T
+        try:
+            L = np.linalg.cholesky(sym)
+        except np.linalg.LinAlgError:
+            L = np.full_like(sym, np.nan)
+            minor = next(i for i in range(1, n + 1) if not _is_pd(sym[:i, :i]))
+            if int(info[0]) == 0:
+                info[0] = info_offset + minor
+        for b0 in range(0, n, NB):          # lower part + zeroed strict upper of diagonal blocks only
+            b1 = min(n, b0 + NB)
+            a[b0:b1, :b0] = L[b0:b1, :b0]
+            a[b0:b1, b0:b1] = np.tril(L[b0:b1, b0:b1])
+        self._dinv(L, dinv)
+
+    @staticmethod
+    def _dinv(L, dinv):
+        n = L.shape[0]
+        d = dinv.numpy()
+        for i, b0 in enumerate(range(0, n, NB)):
+            b1 = min(n, b0 + NB)
+            blk = np.eye(NB)
+            if np.isfinite(L[b0:b1, b0:b1]).all():
+                blk[: b1 - b0, : b1 - b0] = sla.solve_triangular(L[b0:b1, b0:b1], np.eye(b1 - b0), lower=True)
+            d[i * NB * NB:(i + 1) * NB * NB] = blk.reshape(-1)
+
+    def trsm_right(self, Xp, Lkk, dinv):
+        L = np.tril(Lkk.numpy())
+        x = Xp.numpy()
+        x[...] = sla.solve_triangular(L, x.T, lower=True, check_finite=False).T
+
+    def gemm(self, ta, tb, M, N, K, alpha, A, B, beta, Cm):
+        a = A.numpy()
+        b = B.numpy()
+        opa = a[:K, :M].T if ta else a[:M, :K]
+        opb = b[:N, :K].T if tb else b[:K, :N]
+        c = Cm.numpy()
+        c[:M, :N] = alpha * (opa @ opb) + (beta * c[:M, :N] if beta != 0.0 else 0.0)
+
+    def trsm_left(self, trans, L, dinv, B):
+        l = np.tril(L.numpy())
+        b = B.numpy()
+        b[...] = sla.solve_triangular(l, b, lower=True, trans="T" if trans else "N", check_finite=False)
+
+    def logdet(self, L):
+        return float(np.log(np.diagonal(L.numpy())).sum())
+
+    def dot(self, n, x, y):
+        return float(x.numpy()[:n] @ y.numpy()[:n])
+
+    def gemv_t(self, A, x, y):
+        n, m = A.shape
+        y.numpy()[:m] = A.numpy().T @ x.numpy()[:n]
+
+    def sync(self):
+        pass
+
+
+def _is_pd(a):
+    try:
+        np.linalg.cholesky(a)
+        return True
+    except np.linalg.LinAlgError:
+        return False
