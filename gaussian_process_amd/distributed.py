@@ -33,6 +33,11 @@ def owner_of(block_index, world):
     return block_index % world
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 class GpuOps:
     """Local kernels through the C ABI on torch device tensors (views carry pointer + stride)."""
 
@@ -89,6 +94,10 @@ class GpuOps:
         _lib.check(self.lib.gpx_gemv(self.h, 1, A.shape[0], A.shape[1], self._p(A), A.stride(0), self._p(x),
                                      self._p(y)), "gpx_gemv")
 
+    def gemv_n(self, A, x, y):
+        _lib.check(self.lib.gpx_gemv(self.h, 0, A.shape[0], A.shape[1], self._p(A), A.stride(0), self._p(x),
+                                     self._p(y)), "gpx_gemv")
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -100,6 +109,7 @@ class DistributedGP:
         assert block % _lib.GPX_NB == 0, "block must be a multiple of 128"
         self.ops, self.dist, self.rank, self.world, self.block, self.group = ops, dist, rank, world, block, group
         self.torch = ops.torch
+        self._gloo = dist.get_backend(group) == "gloo"
         self.n = 0
 
     # ------------------------------------------------------------------ helpers
@@ -113,16 +123,45 @@ class DistributedGP:
         return self.dinv[lo: lo + ((kb + nb - 1) // nb) * nb * nb]
 
     def _bcast(self, t, src, async_op=False):
-        return self.dist.broadcast(t, src=src, group=self.group, async_op=async_op)
+        """Broadcast a contiguous device buffer.  RCCL: asynchronous on RCCL's stream, ordered after
+        the kernels already enqueued; wait() makes the compute stream wait, not the host.  gloo
+        (rehearsals with several ranks on one GPU, CPU tests): staged through the host and
+        completed before returning."""
+        if t.is_cuda and self._gloo:
+            host = t.cpu()                       # synchronises with the kernels that produced t
+            self.dist.broadcast(host, src=src, group=self.group)
+            if self.rank != src:
+                t.copy_(host)
+            return _Done()
+        w = self.dist.broadcast(t, src=src, group=self.group, async_op=async_op)
+        return w if async_op else _Done()
+
+    def _all_reduce(self, t, op):
+        if t.is_cuda and self._gloo:
+            host = t.cpu()
+            self.dist.all_reduce(host, op=op, group=self.group)
+            return host
+        self.dist.all_reduce(t, op=op, group=self.group)
+        return t
+
+    def _all_gather(self, outs, mine):
+        """all_gather; gloo has no device all_gather, so there it is P broadcasts (test rigs only)."""
+        if mine.is_cuda and self._gloo:
+            for s in range(self.world):
+                if s == self.rank:
+                    outs[s].copy_(mine)
+                self._bcast(outs[s], s)
+        else:
+            self.dist.all_gather(outs, mine, group=self.group)
 
     # ------------------------------------------------------------------ fit
-    def fit(self, X, y, kind, sigma, beta, noise):
-        """Gram + distributed Cholesky + alpha + LML.  X (n, d), y (n,) host arrays, identical on
-        every rank.  Returns (lml, info); the factor stays resident for predict()."""
+    def allocate(self, X, y, kind, sigma, beta, noise):
+        """Upload the (replicated) inputs and allocate everything fit/predict keep resident."""
         ops, t = self.ops, self.torch
         n, d = X.shape
         self.n, self.d = n, d
-        self.kind, self.sigma, self.beta, self.noise = _lib.GPX_KIND[kind], float(sigma), np.asarray(beta, float), float(noise)
+        self.kind, self.sigma, self.noise = _lib.GPX_KIND[kind], float(sigma), float(noise)
+        self.beta = np.asarray(beta, dtype=np.float64).reshape(-1)
         ld = max(32, ((n + 31) // 32) * 32)
         self.A = ops.empty(n, ld)
         self.X = ops.zeros(n, max(32, ((d + 31) // 32) * 32))
@@ -131,6 +170,21 @@ class DistributedGP:
         self.y[:n].copy_(t.from_numpy(np.ascontiguousarray(y, dtype=np.float64)))
         self.dinv = ops.empty(max(((n + 127) // 128) * 128 * 128, 2))
         self.info = ops.zeros(64, dtype=t.int32)
+        b = min(self.block, ((n + 127) // 128) * 128)
+        cap = n * b + ((b + 127) // 128) * 128 * 128
+        self.stg = [ops.empty(cap), ops.empty(cap)]     # double-buffered panel staging
+        self.rhs = ops.zeros(n, 2)
+
+    def upload_test(self, Xs):
+        t = self.torch
+        Xs_d = self.ops.zeros(max(Xs.shape[0], 1), self.X.shape[1])
+        Xs_d[: Xs.shape[0], : self.d].copy_(t.from_numpy(np.ascontiguousarray(Xs, dtype=np.float64)))
+        return Xs_d[: Xs.shape[0]]
+
+    def fit(self, X, y, kind, sigma, beta, noise):
+        """Gram + distributed Cholesky + alpha + LML.  X (n, d), y (n,) host arrays, identical on
+        every rank.  Returns the LML; the factor stays resident on every rank for predict()."""
+        self.allocate(X, y, kind, sigma, beta, noise)
         self.build_gram()
         self.potrf()
         return self.solve_lml()
@@ -169,8 +223,8 @@ class DistributedGP:
     def potrf(self):
         ops, t, n, b = self.ops, self.torch, self.n, self.block
         blocks = self._blocks()
-        cap = n * b + ((b + 127) // 128) * 128 * 128
-        stg = [ops.empty(cap), ops.empty(cap)]
+        stg = self.stg
+        self.info.zero_()
         k, k0, kb = blocks[0]
         if owner_of(0, self.world) == self.rank:
             self._factor_panel(0, k0, kb, stg[0])
@@ -201,7 +255,7 @@ class DistributedGP:
         big = 2 ** 30
         loc = int(self.info[0].item())
         val = t.tensor([loc if loc > 0 else big], dtype=t.int64, device=self.A.device)
-        self.dist.all_reduce(val, op=self.dist.ReduceOp.MIN, group=self.group)
+        val = self._all_reduce(val, self.dist.ReduceOp.MIN)
         self.info_value = 0 if int(val.item()) >= big else int(val.item())
         return self.info_value
 
@@ -210,7 +264,7 @@ class DistributedGP:
         ops, t, n = self.ops, self.torch, self.n
         _lib.check(self.info_value, "distributed potrf")
         L = self.A[:n, :n]
-        rhs = ops.zeros(n, 2)
+        rhs = self.rhs
         rhs[:, 0].copy_(self.y[:n])
         ops.trsm_left(0, L, self.dinv, rhs[:, :1])
         self.a = rhs[:, 0].clone()
@@ -224,13 +278,15 @@ class DistributedGP:
     def predict(self, Xs):
         """regression.py:31-44 with the m test points split over the ranks.  Returns (mean, cov) as
         host arrays on every rank."""
+        mean, cov = self.predict_device(self.upload_test(Xs))
+        return mean.cpu().numpy(), cov.cpu().numpy()
+
+    def predict_device(self, Xs_d):
         ops, t, n, d, P, r = self.ops, self.torch, self.n, self.d, self.world, self.rank
-        m = Xs.shape[0]
+        m = Xs_d.shape[0]
         mc = (m + P - 1) // P
         mc = max(2, mc + (mc & 1))                      # even chunk width (16-byte rows)
         c0, c1 = min(m, r * mc), min(m, (r + 1) * mc)
-        Xs_d = ops.zeros(max(m, 1), self.X.shape[1])
-        Xs_d[:m, :d].copy_(t.from_numpy(np.ascontiguousarray(Xs, dtype=np.float64)))
         L = self.A[:n, :n]
         V = ops.zeros(n, mc)
         if c1 > c0:
@@ -239,10 +295,10 @@ class DistributedGP:
         mean_loc = ops.zeros(mc)
         ops.gemv_t(V, self.a, mean_loc)
         means = [ops.empty(mc) for _ in range(P)]
-        self.dist.all_gather(means, mean_loc, group=self.group)
+        self._all_gather(means, mean_loc)
         mean = t.cat([means[s][: max(0, min(m, (s + 1) * mc) - min(m, s * mc))] for s in range(P)])
         Vs = [ops.empty(n, mc) for _ in range(P)]
-        self.dist.all_gather(Vs, V, group=self.group)
+        self._all_gather(Vs, V)
         mpad = P * mc
         cov_loc = ops.zeros(mc, mpad + (mpad & 1))
         if c1 > c0:
@@ -255,12 +311,30 @@ class DistributedGP:
                          self.noise if s == r else 0.0)
                 ops.gemm(1, 0, c1 - c0, s1 - s0, n, -1.0, V, Vs[s], 1.0, blk)
         covs = [ops.empty(mc, cov_loc.shape[1]) for _ in range(P)]
-        self.dist.all_gather(covs, cov_loc, group=self.group)
+        self._all_gather(covs, cov_loc)
         rows = []
         for s in range(P):
             s0, s1 = min(m, s * mc), min(m, (s + 1) * mc)
             if s1 > s0:
                 rows.append(t.cat([covs[s][: s1 - s0, q * mc: q * mc + max(0, min(m, (q + 1) * mc) - min(m, q * mc))]
                                    for q in range(P)], dim=1))
-        cov = t.cat(rows, dim=0)
-        return mean.cpu().numpy(), cov.cpu().numpy()
+        return mean, t.cat(rows, dim=0)
+
+    # ------------------------------------------------------------------ checks
+    def residual(self):
+        """|| Ky alpha - y || / || y || with Ky rebuilt row slab by row slab (a size-independent
+        parity property for the full-size runs; overwrites the factor)."""
+        ops, t, n, d, P, r = self.ops, self.torch, self.n, self.d, self.world, self.rank
+        rows = ((n + P - 1) // P + 1) // 2 * 2
+        r0, r1 = min(n, r * rows), min(n, (r + 1) * rows)
+        part = t.zeros(2, dtype=t.float64, device=self.A.device)
+        if r1 > r0:
+            slab = self.A[r0:r1, :n]
+            ops.gram(self.kind, self.sigma, self.beta, self.X[r0:r1, :d], self.X[:, :d], slab, 0.0)
+            out = ops.zeros(max(r1 - r0, 2))
+            ops.gemv_n(slab, self.alpha, out)
+            res = out[: r1 - r0] + self.noise * self.alpha[r0:r1] - self.y[r0:r1]
+            part[0] = (res * res).sum()
+            part[1] = (self.y[r0:r1] ** 2).sum()
+        part = self._all_reduce(part, self.dist.ReduceOp.SUM)
+        return float((part[0] / part[1]).sqrt().item())

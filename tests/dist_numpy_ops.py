@@ -88,6 +88,10 @@ class NumpyOps:
         n, m = A.shape
         y.numpy()[:m] = A.numpy().T @ x.numpy()[:n]
 
+    def gemv_n(self, A, x, y):
+        n, m = A.shape
+        y.numpy()[:n] = A.numpy() @ x.numpy()[:m]
+
     def sync(self):
         pass
 

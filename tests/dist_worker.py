@@ -1,0 +1,118 @@
+"""Shared launcher for the multi-rank tests: spawns `world` processes that run
+gaussian_process_amd.distributed.DistributedGP under gloo, with either the NumPy test double
+(CPU, tests/test_dist_cpu.py) or the real libgpx kernels on cuda:0 (tests/test_gpu_dist.py; all
+ranks share the one GPU of the box), and compares every rank's results with the oracle."""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def worker(rank, world, port, case, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)   # a stuck rank names its frame and dies
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        from gaussian_process_amd.distributed import DistributedGP, GpuOps
+        from oracle import gp_oracle as orc
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        n, m, d, block, kind = case["n"], case["m"], case["d"], case["block"], case["kind"]
+        X, y, Xs, _ = orc.synthetic_ard(n, m, d, seed=case.get("seed", 3))
+        sigma, noise = 1.3, case.get("noise", 0.05)
+        beta = 0.5 * np.logspace(-1, 0, d) if kind == "ard" else np.array([0.7])
+        if case.get("gpu"):
+            from gaussian_process_amd.device import runtime
+            torch.cuda.set_device(0)
+            rt = runtime(0)
+            rt.bind_stream()
+            ops = GpuOps(rt)
+        else:
+            from dist_numpy_ops import NumpyOps
+            ops = NumpyOps()
+        host = lambda x: x.detach().cpu().numpy()
+        gp = DistributedGP(ops, dist, rank, world, block=block)
+        out = {"rank": rank}
+        if case.get("expect_fail"):
+            try:
+                gp.fit(X, y, kind, sigma, beta, noise)
+                out["raised"] = None
+            except np.linalg.LinAlgError as e:
+                out["raised"] = str(e)
+            out["info"] = gp.info_value
+        else:
+            lml = gp.fit(X, y, kind, sigma, beta, noise)
+            mean, cov = gp.predict(Xs)
+            L = np.tril(host(gp.A[:n, :n]))
+            Lo = orc.gpr_factor(kind, X, sigma, beta, noise)
+            lml_o, a_o, _ = orc.gpr_lml(kind, X, y, sigma, beta, noise, L=Lo)
+            mean_o, cov_o = orc.gpr_predict(kind, X, y, Xs, sigma, beta, noise, L=Lo)
+            rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+            out.update(L=rel(L, Lo), lml=abs(lml - lml_o) / abs(lml_o), alpha=rel(host(gp.alpha)[:n], orc.gpr_alpha(Lo, y)),
+                       mean=rel(mean, mean_o), cov=rel(cov, cov_o), shapes=(mean.shape, cov.shape))
+            # the diagonal-block inverses every rank keeps must match the factor it keeps
+            nb = 128
+            worst = 0.0
+            for i, b0 in enumerate(range(0, n, nb)):
+                b1 = min(n, b0 + nb)
+                blk = host(gp.dinv[i * nb * nb:(i + 1) * nb * nb]).reshape(nb, nb)[: b1 - b0, : b1 - b0]
+                worst = max(worst, float(np.abs(blk @ Lo[b0:b1, b0:b1] - np.eye(b1 - b0)).max()))
+            out["dinv"] = worst
+            out["res"] = gp.residual()          # last: it overwrites the factor
+        q.put(out)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put({"rank": rank, "error": traceback.format_exc()})
+
+
+def run(world, case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    outs, deadline = [], time.monotonic() + 150
+    while len(outs) < world:
+        try:
+            outs.append(q.get(timeout=1.0))
+            continue
+        except queue.Empty:
+            pass
+        dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+        if dead or time.monotonic() > deadline:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+            raise AssertionError("ranks died or timed out without a result: exit codes %s, got %d/%d results"
+                                 % ([p.exitcode for p in procs], len(outs), world))
+    for p in procs:
+        p.join(timeout=60)
+    codes = [p.exitcode for p in procs]
+    assert codes == [0] * world, "rank exit codes %s" % codes
+    for o in outs:
+        assert "error" not in o, o.get("error")
+    return sorted(outs, key=lambda o: o["rank"])
+
+

@@ -1,0 +1,41 @@
+"""The multi-rank path with the REAL kernels: DistributedGP + GpuOps (libgpx through the C ABI),
+2 and 3 ranks under gloo sharing cuda:0 (the box has one GPU; RCCL refuses two ranks on one
+device, so the collective transport here is gloo -- the kernels, staging, look-ahead and views
+are the ones bench.py --gpus N runs over RCCL).  Compared with the oracle on every rank."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dist_worker import run as _run
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(n=1536, m=100, d=8, block=256, kind="ard", gpu=True),
+    dict(n=1000, m=33, d=3, block=128, kind="ard", gpu=True),     # ragged last block, ragged m
+    dict(n=2049, m=64, d=1, block=512, kind="rbf", gpu=True),     # odd n: last block is one row
+    dict(n=100, m=5, d=2, block=128, kind="ard", gpu=True),       # one block: rank 1 owns nothing
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_b%d_%s" % (c["n"], c["block"], c["kind"]))
+def test_world2_gpu_matches_oracle(case):
+    for o in _run(2, case):
+        assert o["shapes"] == ((case["m"],), (case["m"], case["m"]))
+        assert o["L"] < 1e-12 and o["dinv"] < 1e-9, o
+        assert o["lml"] < 1e-11 and o["alpha"] < 1e-9, o
+        assert o["mean"] < 1e-9 and o["cov"] < 1e-9 and o["res"] < 1e-10, o
+
+
+def test_world3_gpu_matches_oracle():
+    for o in _run(3, dict(n=3000, m=50, d=8, block=256, kind="ard", gpu=True)):
+        assert o["L"] < 1e-12 and o["lml"] < 1e-11 and o["mean"] < 1e-9 and o["cov"] < 1e-9, o
+
+
+def test_world2_gpu_not_positive_definite():
+    outs = _run(2, dict(n=700, m=4, d=2, block=128, kind="ard", noise=-0.5, expect_fail=True, gpu=True))
+    assert outs[0]["info"] > 0 and outs[0]["info"] == outs[1]["info"]
+    for o in outs:
+        assert o["raised"] is not None and "not positive definite" in o["raised"]

@@ -170,6 +170,34 @@ def test_potrf_reports_leading_minor(rt, n, bad):
         _lib.check(rc, "potrf")
 
 
+@pytest.mark.parametrize("n,m", [(128, 64), (300, 517), (1000, 33), (1, 5)])
+def test_potrf_async_and_trsm_right(rt, n, m):
+    """The panel step of a blocked Cholesky as the multi-GPU driver issues it: factor a diagonal
+    block without a host sync (info stays on the device), then X <- X L^-T for the rows below."""
+    import torch
+    A = spd(n, 11)
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((m, n))
+    dA, dX, dinv = up(rt, A), up(rt, X), rt.dinv(n)
+    info = torch.zeros(4, dtype=torch.int32, device=rt.dev)
+    ok(rt.lib.gpx_potrf_async(rt.h, n, P(dA), dA.shape[1], P(dinv), P(info), 1000))
+    ok(rt.lib.gpx_trsm_right(rt.h, m, n, P(dA), dA.shape[1], P(dinv), P(dX), dX.shape[1]))
+    assert int(info[0].item()) == 0
+    L = sla.cholesky(A, lower=True)
+    assert relerr(np.tril(down(rt, dA, n, n)), L) < 1e-13
+    want = sla.solve_triangular(L, X.T, lower=True).T
+    assert relerr(down(rt, dX, m, n), want) < 1e-11
+    # failure: first bad minor, offset by the caller's global row offset; later failures don't overwrite
+    B = spd(max(n, 2), 12)
+    nb = B.shape[0]
+    B[nb - 1, nb - 1] = -1.0
+    dB = up(rt, B)
+    ok(rt.lib.gpx_potrf_async(rt.h, nb, P(dB), dB.shape[1], P(rt.dinv(nb)), P(info), 1000))
+    dB2 = up(rt, -np.eye(nb))
+    ok(rt.lib.gpx_potrf_async(rt.h, nb, P(dB2), dB2.shape[1], P(rt.dinv(nb)), P(info), 5000))
+    assert int(info[0].item()) == 1000 + nb
+
+
 def test_bad_arguments_are_rejected_not_faulted(rt):
     from gaussian_process_amd import _lib
     A = up(rt, spd(8, 1))
