@@ -148,10 +148,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=65536)
-    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--ntrain", "--n", dest="n", type=int, default=65536)   # (torchrun mis-parses a bare --n)
+    ap.add_argument("--ntest", "--m", dest="m", type=int, default=4096)
     ap.add_argument("--cpu-n", type=int, default=8192)
-    ap.add_argument("--block", type=int, default=2048, help="block-column width of the multi-GPU Cholesky")
+    ap.add_argument("--block", type=int, default=0,
+                    help="block-column width of the multi-GPU Cholesky (0: 2048 on 1 rank, 1024 on more)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -159,7 +160,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("GPX_FORCE_DIST"):   # env: run the N>1 code on 1 rank
         from gaussian_process_amd import dist_bench
         return dist_bench.main(args, rank, local_rank, world)
 
