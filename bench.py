@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+# Fabric-side traffic of ONE dominant launch (M=N=K=16384), from rocprofv3 PMC passes of tools/gemm_launch.py
+# (profiles/r01_gemm_launch_pmc_*.csv): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB -> bytes.  The counter
+# sits on the L2's memory side, so Infinity-Cache hits are included: it is an upper bound on HBM bytes.
+GEMM_LAUNCH_TRAFFIC_BYTES = int((2 * 95.08e6 + 2.097152e6) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -112,6 +116,33 @@ def residual_checks(rt, lib, bufs, cfg, check):
     check(lib.gpx_gemv(rt.h, 0, n, n, P(Ky), ld, P(bufs["alpha"]), P(r)), "gemv")
     res = (r[:n] - y[:n]).norm().item() / y[:n].norm().item()
     return res
+
+
+def dominant_launch(rt, lib, bufs, check, torch, size=16384, reps=3):
+    """One launch of the dominant kernel at a shape the factorisation issues (the A22 -= A21 A21^T
+    update of a 32768 split is this shape, lower tiles only): D = C - A B^T, M = N = K = size,
+    timed by HIP events on the launch stream.  Algorithmic flops 2 M N K; algorithmic bytes
+    8 (MK + NK + 2 MN) (operands once, C read + written)."""
+    Kinv, Ky = bufs["Kinv"], bufs["Ky"]
+    ld = Ky.shape[1]
+    a = Kinv[:size, :size]
+    b = Kinv[size:2 * size, :size]
+    c = Ky[:size, size:2 * size]            # strictly upper part of the Ky buffer: scratch here
+    c.zero_()
+    ms = []
+    for _ in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.gpx_gemm(rt.h, 0, 1, size, size, size, -1.0, P(a), ld, P(b), ld, 1.0, P(c), ld), "gemm")
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    t = sum(ms[1:]) / reps
+    flops = 2.0 * size ** 3
+    return {"kernel": "gemm_f64_kernel<KC,KC,4,4>", "shape": "M=N=K=%d, D = C - A B^T" % size,
+            "avg_ms": round(t, 3), "tflops": round(flops / t / 1e9, 2),
+            "frac": round(flops / t / 1e9 / FP64_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_bytes": 8 * 4 * size * size}
 
 
 def cpu_baseline(n_cpu, m_cpu):
@@ -202,6 +233,7 @@ def main():
     potrf_tflops = n ** 3 / 3 / potrf_s / 1e12
     total_flops = n ** 3 / 3 + n * n * m + n * m * m + 2 * n ** 3 / 3
     gram_bytes = 4.0 * n * (n + 1) + 8.0 * n * d       # lower triangle written + X read
+    launch = dominant_launch(rt, lib, bufs, check, torch) if n >= 32768 else None
     res = residual_checks(rt, lib, bufs, cfg, check)
     mean_h = rt.download(bufs["mean"][:m])
     out = {
@@ -218,7 +250,9 @@ def main():
         "stages_ms": {k: round(v, 3) for k, v in stages.items()},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (potrf phase: n^3/3 flops over all launches)",
                      "achieved": round(potrf_tflops, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(potrf_tflops / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None},
+                     "frac": round(potrf_tflops / FP64_MFMA_PEAK_TFLOPS, 4),
+                     "traffic": GEMM_LAUNCH_TRAFFIC_BYTES if launch else None,
+                     "launch": launch},
         "gram_roofline": {"bound": "hbm", "achieved": round(gram_bytes / (stages["gram"] / 1e3) / 1e9, 1),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(gram_bytes / (stages["gram"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)},
