@@ -19,7 +19,43 @@ namespace {
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int GT_ROWS = 64, GT_COLS = 128, GT_THREADS = 256;
+constexpr int GT_ROWS = 64, GT_COLS = 128, GT_THREADS = 256, GT_SUBS = 4;
+
+// exp(x) for x <= 0 (the only argument range a stationary kernel produces): Cody-Waite reduction
+// x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial in Horner form (truncation 4e-18
+// relative), scaling by v_ldexp_f64 (gradual underflow to 0 below x = -745).  19 fp64 VALU
+// instructions against ~45 for the general-range library routine: the Gram kernel is priced
+// against HBM, and at d = 8 the library exp alone kept it VALU-bound.  Max error < 1 ulp + the
+// rounding of the final ldexp (exact unless denormal).
+// Horner step with the coefficient in an SGPR pair: p*r + c as ONE v_fma_f64.  (Left to itself the
+// compiler keeps the 11 non-inline coefficients in VGPRs and pairs every v_fmac with a v_mov_b64,
+// which doubles the instruction count of the polynomial.)
+__device__ __forceinline__ double horner(double p, double r, double c) {
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+  return o;
+}
+
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = x < -800.0 ? -800.0 : x;   // (NaN stays NaN)
+  const double kf = rint(x * 1.44269504088896338700e+00);
+  double r = fma(kf, -6.93147180369123816490e-01, x);
+  r = fma(kf, -1.90821492927058770002e-10, r);
+  double p = horner(1.6059043836821613e-10, r, 2.08767569878681e-09);   // 1/13!, 1/12!
+  p = horner(p, r, 2.505210838544172e-08);         // 1/11!
+  p = horner(p, r, 2.755731922398589e-07);         // 1/10!
+  p = horner(p, r, 2.7557319223985893e-06);        // 1/9!
+  p = horner(p, r, 2.48015873015873e-05);          // 1/8!
+  p = horner(p, r, 1.984126984126984e-04);         // 1/7!
+  p = horner(p, r, 1.388888888888889e-03);         // 1/6!
+  p = horner(p, r, 8.333333333333333e-03);         // 1/5!
+  p = horner(p, r, 4.1666666666666664e-02);        // 1/4!
+  p = horner(p, r, 1.6666666666666666e-01);        // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
+}
 
 struct GramArgs {
   const double* X1; long ldx1; int n1;
@@ -34,16 +70,19 @@ struct GramArgs {
 // D > 0: compile-time dimension (unrolled, registers); D == 0: runtime d <= GPX_MAXD.
 template <int D>
 __global__ __launch_bounds__(GT_THREADS) void gram_kernel(const GramArgs a) {
-  __shared__ double sx1[GT_ROWS * GPX_MAXD];
+  // One workgroup owns GT_SUBS row sub-tiles (64 rows each) of one 128-column strip: the per-lane
+  // X2 rows (registers) and one LDS fill serve 256 KiB of output, so the prologue's load latency
+  // is paid once per four tiles.
+  __shared__ double sx1[GT_SUBS * GT_ROWS * (D > 0 ? D : GPX_MAXD)];
   const int d = D > 0 ? D : a.d;
-  const int r0 = blockIdx.y * GT_ROWS, c0 = blockIdx.x * GT_COLS;
-  if (a.lower && c0 > r0 + GT_ROWS - 1) return;  // tile strictly above the diagonal
+  const int rb = blockIdx.y * (GT_SUBS * GT_ROWS), c0 = blockIdx.x * GT_COLS;
+  if (a.lower && c0 > rb + GT_SUBS * GT_ROWS - 1) return;  // every sub-tile strictly above the diagonal
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
 
-  for (int e = t; e < GT_ROWS * d; e += GT_THREADS) {
+  for (int e = t; e < GT_SUBS * GT_ROWS * d; e += GT_THREADS) {
     const int r = e / d, k = e - r * d;
-    const int gr = r0 + r;
-    sx1[r * d + k] = gr < a.n1 ? a.X1[(long)gr * a.ldx1 + k] * a.sb.b[k] : 0.0;
+    const int gr = rb + r;
+    sx1[e] = gr < a.n1 ? a.X1[(long)gr * a.ldx1 + k] * a.sb.b[k] : 0.0;
   }
   const int c = c0 + 2 * lane;
   double z0[D > 0 ? D : GPX_MAXD], z1[D > 0 ? D : GPX_MAXD];
@@ -56,33 +95,65 @@ __global__ __launch_bounds__(GT_THREADS) void gram_kernel(const GramArgs a) {
   }
   __syncthreads();
 
-  for (int rr = 0; rr < 16; ++rr) {
-    const int r = wid * 16 + rr;
-    const int gr = r0 + r;
-    if (gr >= a.n1) break;
-    double s0 = 0.0, s1 = 0.0;
+  for (int sub = 0; sub < GT_SUBS; ++sub) {
+    const int r0 = rb + sub * GT_ROWS;
+    if (r0 >= a.n1) break;
+    if (a.lower && c0 > r0 + GT_ROWS - 1) continue;  // tile strictly above the diagonal: not touched
+    const double* xs = sx1 + sub * GT_ROWS * d;
+    // interior tiles (no matrix edge, no diagonal inside): no selects, no bounds tests
+    const bool touches_diag = c0 < r0 + GT_ROWS && r0 < c0 + GT_COLS;
+    const bool interior = r0 + GT_ROWS <= a.n1 && c0 + GT_COLS <= a.n2 &&
+                          !(touches_diag && (a.lower || a.diag_add != 0.0));
+    if (interior) {
+      double* dst = a.K + (long)(r0 + wid * 16) * a.ldk + c;
+#pragma unroll 2
+      for (int rr = 0; rr < 16; ++rr) {
+        const double* xr = xs + (wid * 16 + rr) * d;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
-      if (k < d) {
-        const double x = sx1[r * d + k];
-        const double d0 = x - z0[k], d1 = x - z1[k];
-        s0 = fma(d0, d0, s0);
-        s1 = fma(d1, d1, s1);
+        for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
+          if (k < d) {
+            const double x = xr[k];
+            const double d0 = x - z0[k], d1 = x - z1[k];
+            s0 = fma(d0, d0, s0);
+            s1 = fma(d1, d1, s1);
+          }
+        }
+        const double k0 = a.sigma * exp_nonpos(-0.5 * s0);
+        const double k1 = a.sigma * exp_nonpos(-0.5 * s1);
+        *reinterpret_cast<v2d*>(dst) = (v2d){k0, k1};
+        dst += a.ldk;
       }
+      continue;
     }
-    double k0 = a.sigma * exp(-0.5 * s0);
-    double k1 = a.sigma * exp(-0.5 * s1);
-    if (gr == c) k0 += a.diag_add;
-    if (gr == c + 1) k1 += a.diag_add;
-    if (a.lower) {
-      if (c > gr) k0 = 0.0;
-      if (c + 1 > gr) k1 = 0.0;
-    }
-    double* dst = a.K + (long)gr * a.ldk + c;
-    if (c + 1 < a.n2) {
-      *reinterpret_cast<v2d*>(dst) = (v2d){k0, k1};
-    } else if (c < a.n2) {
-      dst[0] = k0;
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = wid * 16 + rr;
+      const int gr = r0 + r;
+      if (gr >= a.n1) break;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
+        if (k < d) {
+          const double x = xs[r * d + k];
+          const double d0 = x - z0[k], d1 = x - z1[k];
+          s0 = fma(d0, d0, s0);
+          s1 = fma(d1, d1, s1);
+        }
+      }
+      double k0 = a.sigma * exp_nonpos(-0.5 * s0);
+      double k1 = a.sigma * exp_nonpos(-0.5 * s1);
+      if (gr == c) k0 += a.diag_add;
+      if (gr == c + 1) k1 += a.diag_add;
+      if (a.lower) {
+        if (c > gr) k0 = 0.0;
+        if (c + 1 > gr) k1 = 0.0;
+      }
+      double* dst = a.K + (long)gr * a.ldk + c;
+      if (c + 1 < a.n2) {
+        *reinterpret_cast<v2d*>(dst) = (v2d){k0, k1};
+      } else if (c < a.n2) {
+        dst[0] = k0;
+      }
     }
   }
 }
@@ -202,8 +273,8 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
       }
       const double A0 = ai * al0 - q0;
       const double A1 = v1 ? ai * al1 - q1 : 0.0;
-      const double w0 = (c == gr ? 1.0 : 2.0) * A0 * exp(-0.5 * s0);
-      const double w1 = v1 ? (c + 1 == gr ? 1.0 : 2.0) * A1 * exp(-0.5 * s1) : 0.0;
+      const double w0 = (c == gr ? 1.0 : 2.0) * A0 * exp_nonpos(-0.5 * s0);
+      const double w1 = v1 ? (c + 1 == gr ? 1.0 : 2.0) * A1 * exp_nonpos(-0.5 * s1) : 0.0;
       if (c == gr) acc[0] += A0;
       if (c + 1 == gr) acc[0] += A1;
       acc[1] += w0 + w1;
@@ -269,7 +340,7 @@ int gpx_gram_launch(hipStream_t s, const double* X1, int n1, long ldx1, const do
   a.X2 = X2; a.ldx2 = ldx2; a.n2 = n2;
   a.d = d; a.sigma = sigma; a.diag_add = diag_add; a.K = K; a.ldk = ldk; a.lower = uplo == GPX_LOWER;
   for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(hb.b[k]) : 0.0;
-  dim3 grid((n2 + GT_COLS - 1) / GT_COLS, (n1 + GT_ROWS - 1) / GT_ROWS);
+  dim3 grid((n2 + GT_COLS - 1) / GT_COLS, (n1 + GT_SUBS * GT_ROWS - 1) / (GT_SUBS * GT_ROWS));
   dispatch_d(d, [&](auto D) {
     hipLaunchKernelGGL((gram_kernel<decltype(D)::value>), grid, dim3(GT_THREADS), 0, s, a);
   });
