@@ -38,12 +38,12 @@ __global__ __launch_bounds__(1024) void dot_kernel(int n, const double* x, const
 }
 
 // y[j] = sum_i A[i][j] x[i]   (A n x m row-major).  Stage 1: row chunks -> partials[chunk][m].
-constexpr int GV_ROWS = 256;  // rows per chunk
+constexpr int GV_ROWS = 256;  // rows per chunk (doubled until the partials fit the scratch)
 __global__ __launch_bounds__(256) void gemvT_partial_kernel(int n, int m, const double* A, long lda,
-                                                             const double* x, double* partials) {
+                                                             const double* x, double* partials, int rows) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  const int i0 = blockIdx.y * GV_ROWS;
-  const int i1 = min(n, i0 + GV_ROWS);
+  const int i0 = blockIdx.y * rows;
+  const int i1 = min(n, i0 + rows);
   if (j >= m) return;
   double acc = 0.0;
   for (int i = i0; i < i1; ++i) acc = fma(A[(long)i * lda + j], x[i], acc);
@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256) void gemvN_kernel(int n, int m, const double* 
 
 // var[j] = base - sum_i V[i][j]^2  (diagonal of regression.py:41-44 / expectation_propagation.py:118)
 __global__ __launch_bounds__(256) void colsumsq_partial_kernel(int n, int m, const double* V, long ldv,
-                                                                double* partials) {
+                                                                double* partials, int rows) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  const int i0 = blockIdx.y * GV_ROWS;
-  const int i1 = min(n, i0 + GV_ROWS);
+  const int i0 = blockIdx.y * rows;
+  const int i1 = min(n, i0 + rows);
   if (j >= m) return;
   double acc = 0.0;
   for (int i = i0; i < i1; ++i) {
@@ -141,6 +141,13 @@ __global__ __launch_bounds__(256) void ep_scale_kernel(int n, const double* K, l
 
 }  // namespace
 
+// rows per partial-sum chunk: GV_ROWS, doubled while chunks x m would overflow the scratch
+static int chunk_rows(int n, int m, size_t red_elems) {
+  int rows = GV_ROWS;
+  while ((size_t)((n + rows - 1) / rows) * m > red_elems && rows < (1 << 20)) rows *= 2;
+  return rows;
+}
+
 int gpx_logdet_launch(hipStream_t s, int n, const double* L, long ldl, double*, double* out_dev) {
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, s, n, L, ldl, out_dev);
   GPX_HIP(hipGetLastError());
@@ -157,13 +164,14 @@ int gpx_gemv_launch(hipStream_t s, int trans, int n, int m, const double* A, lon
                     const double* x, double* y, double* red, size_t red_elems) {
   if (n <= 0 || m <= 0) return 0;
   if (trans) {
-    const int nchunks = (n + GV_ROWS - 1) / GV_ROWS;
+    const int rows = chunk_rows(n, m, red_elems);
+    const int nchunks = (n + rows - 1) / rows;
     if ((size_t)nchunks * m > red_elems) {
       gpx_set_error("gemv: reduction scratch too small (%d x %d)", n, m);
       return GPX_ENOMEM;
     }
     dim3 grid((m + 255) / 256, nchunks);
-    hipLaunchKernelGGL(gemvT_partial_kernel, grid, dim3(256), 0, s, n, m, A, lda, x, red);
+    hipLaunchKernelGGL(gemvT_partial_kernel, grid, dim3(256), 0, s, n, m, A, lda, x, red, rows);
     hipLaunchKernelGGL(gemvT_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nchunks, m, red, y);
   } else {
     hipLaunchKernelGGL(gemvN_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, m, A, lda, x, y);
@@ -175,13 +183,14 @@ int gpx_gemv_launch(hipStream_t s, int trans, int n, int m, const double* A, lon
 int gpx_colsumsq_sub_launch(hipStream_t s, int n, int m, const double* V, long ldv, double base,
                             double* var, double* red, size_t red_elems) {
   if (m <= 0) return 0;
-  const int nchunks = (n + GV_ROWS - 1) / GV_ROWS;
+  const int rows = chunk_rows(n, m, red_elems);
+  const int nchunks = (n + rows - 1) / rows;
   if ((size_t)nchunks * m > red_elems) {
     gpx_set_error("colsumsq: reduction scratch too small (%d x %d)", n, m);
     return GPX_ENOMEM;
   }
   dim3 grid((m + 255) / 256, nchunks);
-  hipLaunchKernelGGL(colsumsq_partial_kernel, grid, dim3(256), 0, s, n, m, V, ldv, red);
+  hipLaunchKernelGGL(colsumsq_partial_kernel, grid, dim3(256), 0, s, n, m, V, ldv, red, rows);
   hipLaunchKernelGGL(colsumsq_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nchunks, m, red,
                      base, var);
   GPX_HIP(hipGetLastError());

@@ -189,6 +189,14 @@ constexpr size_t RED_SCALARS = 64;
 inline double* red_scalars(gpx_handle* h) { return h->red + (GPX_RED_ELEMS - RED_SCALARS); }
 constexpr size_t RED_USABLE = GPX_RED_ELEMS - RED_SCALARS;
 
+// B <- L^-1 B / L^-T B: one right-hand side goes to the streaming TRSV (trsv.hip), more to the
+// recursive MFMA TRSM.
+int solve_lower(gpx_handle* h, int trans, int n, int m, const double* L, long ldl, const double* dinv,
+                double* B, long ldb) {
+  if (m == 1) return gpx_trsv_launch(h->stream, trans, n, L, ldl, dinv, B, ldb, h->red, RED_USABLE);
+  return trans ? trsm_ltn(h->stream, n, m, L, ldl, dinv, B, ldb) : trsm_lln(h->stream, n, m, L, ldl, dinv, B, ldb);
+}
+
 }  // namespace
 
 extern "C" {
@@ -337,8 +345,7 @@ int gpx_trsm(gpx_handle* h, int trans, int n, int nrhs, const double* L, int ldl
   GPX_TRY(check_mat("trsm: B", B, ldb, nrhs));
   GPX_REQUIRE(dinv != nullptr && gpx_aligned16(dinv), "trsm: dinv null or misaligned");
   DeviceGuard dg(h->device);
-  return trans ? trsm_ltn(h->stream, n, nrhs, L, ldl, dinv, B, ldb)
-               : trsm_lln(h->stream, n, nrhs, L, ldl, dinv, B, ldb);
+  return solve_lower(h, trans, n, nrhs, L, ldl, dinv, B, ldb);
 }
 
 int gpx_logdet(gpx_handle* h, int n, const double* L, int ldl, double* out_host) {
@@ -486,10 +493,10 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
   GPX_HIP(hipMemsetAsync(rhs, 0, 2L * n * sizeof(double), s));
   GPX_HIP(hipMemcpy2DAsync(rhs, ldv * sizeof(double), y, sizeof(double), sizeof(double), n,
                            hipMemcpyDeviceToDevice, s));
-  GPX_TRY(trsm_lln(s, n, 1, Ky, ldk, dinv, rhs, ldv));
+  GPX_TRY(solve_lower(h, 0, n, 1, Ky, ldk, dinv, rhs, ldv));
   GPX_HIP(hipMemcpy2DAsync(a_vec, sizeof(double), rhs, ldv * sizeof(double), sizeof(double), n,
                            hipMemcpyDeviceToDevice, s));
-  GPX_TRY(trsm_ltn(s, n, 1, Ky, ldk, dinv, rhs, ldv));
+  GPX_TRY(solve_lower(h, 1, n, 1, Ky, ldk, dinv, rhs, ldv));
   GPX_HIP(hipMemcpy2DAsync(al_vec, sizeof(double), rhs, ldv * sizeof(double), sizeof(double), n,
                            hipMemcpyDeviceToDevice, s));
   double* sc = red_scalars(h);
@@ -541,12 +548,12 @@ int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, in
   GPX_HIP(hipMemsetAsync(rhs, 0, 2L * n * sizeof(double), s));
   GPX_HIP(hipMemcpy2DAsync(rhs, 2 * sizeof(double), y, sizeof(double), sizeof(double), n,
                            hipMemcpyDeviceToDevice, s));
-  GPX_TRY(trsm_lln(s, n, 1, L, ldl, dinv, rhs, 2));
+  GPX_TRY(solve_lower(h, 0, n, 1, L, ldl, dinv, rhs, 2));
   GPX_HIP(hipMemcpy2DAsync(a_vec, sizeof(double), rhs, 2 * sizeof(double), sizeof(double), n,
                            hipMemcpyDeviceToDevice, s));
   // k* = K(Xtr, Xs) (regression.py:33), V = L^-1 k* (regression.py:38)
   GPX_TRY(gpx_gram_launch(s, X, n, ldx, Xs, m, ldxs, d, sigma, b, 0.0, V, ldv, GPX_FULL));
-  GPX_TRY(trsm_lln(s, n, m, L, ldl, dinv, V, ldv));
+  GPX_TRY(solve_lower(h, 0, n, m, L, ldl, dinv, V, ldv));
   // mean = a . V (regression.py:39)
   GPX_TRY(gpx_gemv_launch(s, 1, n, m, V, ldv, a_vec, mean, h->red, RED_USABLE));
   if (full_cov) {

@@ -79,6 +79,10 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, int n, long ldx, int d
                           double sigma, const BetaArg& hb, const double* alpha, const double* Kinv,
                           long ldk, double* red, size_t red_elems, double* out_dev);
 
+// trsv.hip: x <- L^-1 x (trans 0) / L^-T x (trans 1) for one strided vector
+int gpx_trsv_launch(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv, double* x,
+                    long incx, double* red, size_t red_elems);
+
 // blas2.hip
 int gpx_logdet_launch(hipStream_t s, int n, const double* L, long ldl, double* red, double* out_dev);
 int gpx_dot_launch(hipStream_t s, int n, const double* x, const double* y, double* red, double* out_dev);

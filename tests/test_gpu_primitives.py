@@ -155,6 +155,29 @@ def test_potrf_trsm_trtri_lauum(rt, n):
     assert relerr(down(rt, Kinv, n, n), np.linalg.inv(A)) < 1e-12
 
 
+@pytest.mark.parametrize("n", [513, 1024, 1153, 4097, 9000])
+def test_trsv_single_rhs(rt, n):
+    """One right-hand side goes through the streaming TRSV (leaf + GEMV recursion), both directions,
+    including strided vectors; the factor here is a generic lower-triangular matrix, not a Cholesky
+    factor (solve_triangular at regression.py:37,50)."""
+    rng = np.random.default_rng(n)
+    L = np.tril(rng.standard_normal((n, n)) / np.sqrt(n))
+    L[np.diag_indices(n)] = 1.0 + rng.random(n)
+    dL, dinv = up(rt, L), rt.dinv(n)
+    ok(rt.lib.gpx_diag_inv(rt.h, n, P(dL), dL.shape[1], P(dinv)))
+    b = rng.standard_normal((n, 1))
+    for trans in (0, 1):
+        ref = sla.solve_triangular(L, b, lower=True, trans="T" if trans else "N")
+        for ldb in (32, 2):
+            import torch
+            dB = torch.zeros((n, ldb), dtype=torch.float64, device=rt.dev)
+            dB[:, :1].copy_(torch.from_numpy(b))
+            ok(rt.lib.gpx_trsm(rt.h, trans, n, 1, P(dL), dL.shape[1], P(dinv), P(dB), ldb))
+            got = rt.download(dB)
+            assert relerr(got[:, :1], ref) < 1e-12
+            assert not got[:, 1:].any()          # neighbours of the strided vector untouched
+
+
 @pytest.mark.parametrize("n,bad", [(10, 4), (300, 0), (300, 131), (300, 299)])
 def test_potrf_reports_leading_minor(rt, n, bad):
     """LAPACK info semantics: first leading minor that is not positive definite (regression.py:36)."""
