@@ -43,6 +43,7 @@ SIGNATURES = {
     "gpx_symmetrize": (_i, [C.c_void_p, _i, _dp, _i]),
     "gpx_diag": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
     "gpx_grad_trace": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _dp, _dp, _i, _hp]),
+    "gpx_grad_trace_slab": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _dp, _dp, _i, _i, _i, _i, _i, _hp]),
     "gpx_gpr_lml_grad": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _dp, _i, _dp, _dp,
                               _dp, _dp, _hp, _hp]),
     "gpx_gpr_predict": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _dp, _i, _i,

@@ -455,8 +455,31 @@ int gpx_grad_trace(gpx_handle* h, int kind, const double* X, int n, int ldx, int
   for (int k = 0; k < nbeta; ++k) GPX_REQUIRE(b.b[k] > 0.0, "grad_trace: beta[%d] must be positive", k);
   DeviceGuard dg(h->device);
   double* sc = red_scalars(h);
-  GPX_TRY(gpx_grad_trace_launch(h->stream, X, n, ldx, d, nbeta, sigma, b, alpha, Kinv, ldk, h->red,
+  GPX_TRY(gpx_grad_trace_launch(h->stream, X, ldx, d, nbeta, sigma, b, alpha, Kinv, ldk, 0, 0, n, n, h->red,
                                 RED_USABLE, sc));
+  double raw[GPX_MAXD + 2];
+  GPX_TRY(fetch(h, sc, raw, 2 + nbeta));
+  return finish_grad(nbeta, sigma, b, raw, out_host);
+}
+
+int gpx_grad_trace_slab(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
+                        const double* beta_host, const double* alpha, const double* Kinv_slab, int ldk,
+                        int row_off, int col_off, int nrows, int ncols, double* out_host) {
+  GPX_REQUIRE(h != nullptr && out_host != nullptr, "grad_trace_slab: null argument");
+  BetaArg b;
+  int nbeta;
+  GPX_TRY(fill_beta(kind, d, beta_host, b, nbeta));
+  GPX_REQUIRE(n > 0 && X && alpha && ldx >= d, "grad_trace_slab: bad arguments");
+  GPX_REQUIRE(row_off >= 0 && col_off >= 0 && nrows > 0 && ncols > 0 && row_off + nrows <= n &&
+                  col_off + ncols <= n && (col_off & 1) == 0,
+              "grad_trace_slab: slab [%d+%d) x [%d+%d) outside the %d x %d matrix (col_off must be even)",
+              row_off, nrows, col_off, ncols, n, n);
+  GPX_TRY(check_mat("grad_trace_slab: Kinv", Kinv_slab, ldk, ncols));
+  for (int k = 0; k < nbeta; ++k) GPX_REQUIRE(b.b[k] > 0.0, "grad_trace_slab: beta[%d] must be positive", k);
+  DeviceGuard dg(h->device);
+  double* sc = red_scalars(h);
+  GPX_TRY(gpx_grad_trace_launch(h->stream, X, ldx, d, nbeta, sigma, b, alpha, Kinv_slab, ldk, row_off, col_off,
+                                nrows, ncols, h->red, RED_USABLE, sc));
   double raw[GPX_MAXD + 2];
   GPX_TRY(fetch(h, sc, raw, 2 + nbeta));
   return finish_grad(nbeta, sigma, b, raw, out_host);
@@ -511,7 +534,7 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
     GemmDesc g = mk(Ky, ldk, GPX_LAY_RC, Ky, ldk, GPX_LAY_RC, nullptr, 0, Kinv, ldk, n, n, n, 1.0, 0.0);
     g.a_tri = g.b_tri = g.c_lower = 1;
     GPX_TRY(gpx_gemm_launch(s, g));
-    GPX_TRY(gpx_grad_trace_launch(s, X, n, ldx, d, nbeta, sigma, b, al_vec, Kinv, ldk, h->red, RED_USABLE,
+    GPX_TRY(gpx_grad_trace_launch(s, X, ldx, d, nbeta, sigma, b, al_vec, Kinv, ldk, 0, 0, n, n, h->red, RED_USABLE,
                                   sc + 2));
     nfetch = 4 + nbeta;
   }

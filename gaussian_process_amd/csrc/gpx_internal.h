@@ -75,9 +75,9 @@ int gpx_gram_launch(hipStream_t s, const double* X1, int n1, long ldx1, const do
 int gpx_gram_dtheta_launch(hipStream_t s, const double* X1, int n1, long ldx1, const double* X2,
                            int n2, long ldx2, int d, int nbeta, double sigma, const BetaArg& hb,
                            double* K, double* dsigma, double* dbeta, long ld, size_t plane);
-int gpx_grad_trace_launch(hipStream_t s, const double* X, int n, long ldx, int d, int nbeta,
-                          double sigma, const BetaArg& hb, const double* alpha, const double* Kinv,
-                          long ldk, double* red, size_t red_elems, double* out_dev);
+int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int nbeta, double sigma,
+                          const BetaArg& hb, const double* alpha, const double* Kinv, long ldk, int roff,
+                          int coff, int nr, int nc, double* red, size_t red_elems, double* out_dev);
 
 // trsv.hip: x <- L^-1 x (trans 0) / L^-T x (trans 1) for one strided vector
 int gpx_trsv_launch(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv, double* x,

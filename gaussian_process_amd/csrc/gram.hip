@@ -196,8 +196,10 @@ __global__ void gram_dtheta_kernel(const DthetaArgs a) {
 // grad-trace: sums over the lower triangle of A = alpha alpha^T - Kinv against K and diff_k K.
 // Partials per workgroup -> fixed-order final reduction (bitwise reproducible).
 // ---------------------------------------------------------------------------------------
+// The weights cover a slab of the symmetric matrix: local (r, c) is global (roff + r, coff + c),
+// nr x nc local elements, Kinv points at the slab.  The full matrix is roff = coff = 0, nr = nc = n.
 struct TraceArgs {
-  const double* X; long ldx; int n; int d; int nbeta;
+  const double* X; long ldx; int nr, nc, roff, coff; int d; int nbeta;
   double sigma;
   const double* alpha; const double* Kinv; long ldk;
   double* partials;  // [nblocks][nacc]
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
   const int r0 = blockIdx.y * GT_ROWS, c0 = blockIdx.x * GT_COLS;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-  const bool skip = c0 > r0 + GT_ROWS - 1;
+  const bool skip = a.coff + c0 > a.roff + r0 + GT_ROWS - 1;   // tile strictly above the diagonal
 
   // acc[0]: sum A_ii (diag)   acc[1]: sum w A_ij K_ij   acc[2+k]: sum w A_ij K_ij z-diff_k^2
   double acc[2 + (D > 0 ? D : GPX_MAXD)];
@@ -226,30 +228,32 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
   if (!skip) {
     for (int e = t; e < GT_ROWS * d; e += GT_THREADS) {
       const int r = e / d, k = e - r * d;
-      const int gr = r0 + r;
-      sx1[r * d + k] = gr < a.n ? a.X[(long)gr * a.ldx + k] * a.sb.b[k] : 0.0;
+      const int lr = r0 + r;
+      sx1[r * d + k] = lr < a.nr ? a.X[(long)(a.roff + lr) * a.ldx + k] * a.sb.b[k] : 0.0;
     }
-    if (t < GT_ROWS) sal[t] = (r0 + t) < a.n ? a.alpha[r0 + t] : 0.0;
-    const int c = c0 + 2 * lane;
+    if (t < GT_ROWS) sal[t] = (r0 + t) < a.nr ? a.alpha[a.roff + r0 + t] : 0.0;
+    const int c = c0 + 2 * lane;          // local column
+    const int gc = a.coff + c;            // global column
     double z0[D > 0 ? D : GPX_MAXD], z1[D > 0 ? D : GPX_MAXD];
 #pragma unroll
     for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
       if (k < d) {
-        z0[k] = c < a.n ? a.X[(long)c * a.ldx + k] * a.sb.b[k] : 0.0;
-        z1[k] = c + 1 < a.n ? a.X[(long)(c + 1) * a.ldx + k] * a.sb.b[k] : 0.0;
+        z0[k] = c < a.nc ? a.X[(long)gc * a.ldx + k] * a.sb.b[k] : 0.0;
+        z1[k] = c + 1 < a.nc ? a.X[(long)(gc + 1) * a.ldx + k] * a.sb.b[k] : 0.0;
       }
     }
-    const double al0 = c < a.n ? a.alpha[c] : 0.0;
-    const double al1 = c + 1 < a.n ? a.alpha[c + 1] : 0.0;
+    const double al0 = c < a.nc ? a.alpha[gc] : 0.0;
+    const double al1 = c + 1 < a.nc ? a.alpha[gc + 1] : 0.0;
     __syncthreads();
     for (int rr = 0; rr < 16; ++rr) {
       const int r = wid * 16 + rr;
-      const int gr = r0 + r;
-      if (gr >= a.n) break;
-      if (c > gr) continue;  // both columns above the diagonal
-      const double* src = a.Kinv + (long)gr * a.ldk + c;
+      const int lr = r0 + r;
+      if (lr >= a.nr) break;
+      const int gr = a.roff + lr;
+      if (gc > gr || c >= a.nc) continue;  // both columns above the diagonal / outside the slab
+      const double* src = a.Kinv + (long)lr * a.ldk + c;
       double q0 = 0.0, q1 = 0.0;
-      const bool v1 = (c + 1 <= gr);  // c + 1 < n follows from gr < n
+      const bool v1 = (gc + 1 <= gr) && (c + 1 < a.nc);
       if (v1) {
         const v2d q = *reinterpret_cast<const v2d*>(src);
         q0 = q[0];
@@ -273,10 +277,10 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
       }
       const double A0 = ai * al0 - q0;
       const double A1 = v1 ? ai * al1 - q1 : 0.0;
-      const double w0 = (c == gr ? 1.0 : 2.0) * A0 * exp_nonpos(-0.5 * s0);
-      const double w1 = v1 ? (c + 1 == gr ? 1.0 : 2.0) * A1 * exp_nonpos(-0.5 * s1) : 0.0;
-      if (c == gr) acc[0] += A0;
-      if (c + 1 == gr) acc[0] += A1;
+      const double w0 = (gc == gr ? 1.0 : 2.0) * A0 * exp_nonpos(-0.5 * s0);
+      const double w1 = v1 ? (gc + 1 == gr ? 1.0 : 2.0) * A1 * exp_nonpos(-0.5 * s1) : 0.0;
+      if (gc == gr) acc[0] += A0;
+      if (v1 && gc + 1 == gr) acc[0] += A1;
       acc[1] += w0 + w1;
       if (a.nbeta == 1) {
         acc[2] += w0 * s0 + w1 * s1;  // RBF: sum_k beta (x-x')^2 ; divided by beta on the host
@@ -362,18 +366,18 @@ int gpx_gram_dtheta_launch(hipStream_t s, const double* X1, int n1, long ldx1, c
   return 0;
 }
 
-int gpx_grad_trace_launch(hipStream_t s, const double* X, int n, long ldx, int d, int nbeta,
-                          double sigma, const BetaArg& hb, const double* alpha, const double* Kinv,
-                          long ldk, double* red, size_t red_elems, double* out_dev) {
+int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int nbeta, double sigma,
+                          const BetaArg& hb, const double* alpha, const double* Kinv, long ldk, int roff,
+                          int coff, int nr, int nc, double* red, size_t red_elems, double* out_dev) {
   TraceArgs a;
-  a.X = X; a.ldx = ldx; a.n = n; a.d = d; a.nbeta = nbeta; a.sigma = sigma;
-  a.alpha = alpha; a.Kinv = Kinv; a.ldk = ldk; a.partials = red;
+  a.X = X; a.ldx = ldx; a.nr = nr; a.nc = nc; a.roff = roff; a.coff = coff; a.d = d; a.nbeta = nbeta;
+  a.sigma = sigma; a.alpha = alpha; a.Kinv = Kinv; a.ldk = ldk; a.partials = red;
   for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(hb.b[k]) : 0.0;
-  dim3 grid((n + GT_COLS - 1) / GT_COLS, (n + GT_ROWS - 1) / GT_ROWS);
+  dim3 grid((nc + GT_COLS - 1) / GT_COLS, (nr + GT_ROWS - 1) / GT_ROWS);
   const size_t nblocks = (size_t)grid.x * grid.y;
   const int nacc = 2 + nbeta;
   if (nblocks * nacc > red_elems) {
-    gpx_set_error("grad_trace: reduction scratch too small for n=%d", n);
+    gpx_set_error("grad_trace: reduction scratch too small for a %d x %d slab", nr, nc);
     return GPX_ENOMEM;
   }
   dispatch_d(d, [&](auto D) {

@@ -1,8 +1,9 @@
 """bench.py's N > 1 leg: one rank per GPU, RCCL, strong scaling at fixed n (BASELINE configs[3]).
 
-A step is the same fit+predict pass as at N = 1 without the gradient stage (which round 1 does not
-distribute): Gram of the owned block columns, distributed potrf (distributed.py), replicated
-alpha / LML, predict split over the test columns.  value = n^3/3 / (potrf time, max over ranks)."""
+A step is the same fit+predict pass as at N = 1: Gram of the owned block
+columns, distributed potrf (distributed.py), replicated alpha / LML, predict split over the test
+columns, and the LML gradient from per-owner block columns of Ky^-1.
+value = n^3/3 / (potrf time, max over ranks)."""
 import json
 import os
 import time
@@ -53,7 +54,9 @@ def main(args, rank, local_rank, world):
         mark("solve_lml")
         mean, cov = gp.predict_device(gp_Xs)
         mark("predict")
-        return lml, mean, cov
+        grad = gp.grad()
+        mark("grad")
+        return lml, mean, cov, grad
 
     # allocate once (fit() would also upload): buffers stay resident across steps
     gp.allocate(X, y, "ard", sigma, beta, noise)
@@ -67,7 +70,7 @@ def main(args, rank, local_rank, world):
     all_marks = []
     for _ in range(args.steps):
         mk = []
-        lml, mean, cov = step(mk)
+        lml, mean, cov, grad = step(mk)
         all_marks.append(mk)
     torch.cuda.synchronize()
     dist.barrier()
@@ -77,7 +80,7 @@ def main(args, rank, local_rank, world):
     for mk in all_marks:
         for (n0, e0), (n1, e1) in zip(mk[:-1], mk[1:]):
             stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / args.steps
-    names = ["gram", "potrf", "solve_lml", "predict"]
+    names = ["gram", "potrf", "solve_lml", "predict", "grad"]
     vec = torch.tensor([wall] + [stages[k] for k in names], dtype=torch.float64, device=rt.dev)
     dist.all_reduce(vec, op=dist.ReduceOp.MAX)
     vec = vec.cpu().numpy()
@@ -97,15 +100,17 @@ def main(args, rank, local_rank, world):
             "config": {"workload": "synthetic ARD regression n=%d d=8 m=%d, noise 0.1 (BASELINE configs[3])" % (n, m),
                        "parallelism": "block-column-cyclic x%d, block %d, panel broadcasts (%s), look-ahead 1"
                                       % (world, gp.block, backend),
-                       "step": "gram + potrf + alpha/LML + predict (gradient stage is single-GPU only in round 1)"},
+                       "step": "gram + potrf + alpha/LML + predict + LML gradient (block columns of Ky^-1 per owner)"},
             "fit_predict_wall_s": round(ms / 1e3, 4),
+            "fit_predict_without_gradient_s": round(sum(stages[k] for k in names[:4]) / 1e3, 4),
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (potrf phase, whole job)",
                          "achieved": round(potrf_tflops, 3), "peak": FP64_MFMA_PEAK_TFLOPS * world,
                          "unit": "TFLOP/s", "frac": round(potrf_tflops / (FP64_MFMA_PEAK_TFLOPS * world), 4),
                          "traffic": None},
             "parity": {"lml": lml, "residual_Ky_alpha_minus_y_rel": res,
-                       "mean_finite": bool(np.isfinite(mean.cpu().numpy()).all())},
+                       "mean_finite": bool(np.isfinite(mean.cpu().numpy()).all()),
+                       "grad": [float(g) for g in grad]},
         }
         print(json.dumps(out), flush=True)
     dist.barrier()

@@ -98,6 +98,15 @@ class GpuOps:
         _lib.check(self.lib.gpx_gemv(self.h, 0, A.shape[0], A.shape[1], self._p(A), A.stride(0), self._p(x),
                                      self._p(y)), "gpx_gemv")
 
+    def grad_trace_slab(self, kind, sigma, beta, X, d, alpha, slab, row_off, col_off):
+        barr, bp = _lib.host_doubles(beta)
+        out = (C.c_double * (2 + len(barr)))()
+        _lib.check(self.lib.gpx_grad_trace_slab(self.h, kind, self._p(X), X.shape[0], X.stride(0), d, float(sigma),
+                                                bp, self._p(alpha), self._p(slab), slab.stride(0), int(row_off),
+                                                int(col_off), slab.shape[0], slab.shape[1],
+                                                C.cast(out, C.POINTER(C.c_double))), "gpx_grad_trace_slab")
+        return np.array(list(out))
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -273,6 +282,37 @@ class DistributedGP:
         aa = ops.dot(n, self.a, self.a)
         self.lml = -0.5 * aa - ops.logdet(L) - 0.5 * n * np.log(2.0 * np.pi)
         return self.lml
+
+    # ------------------------------------------------------------------ gradient
+    def grad(self):
+        """regression.py:57-76 without ever forming Ky^-1 whole and without communication: every rank
+        holds all of L, so the owner of block column J computes the part of Ky^-1 on and below the
+        diagonal of J from the trailing sub-factor alone,
+            Kinv[j0:, J] = L[j0:, j0:]^-T ( L[j0:, j0:]^-1 [I; 0] )      ((n - j0)^2 b flops each, 2n^3/3 in all),
+        and adds its share of the trace sums (gpx_grad_trace_slab).  One all-reduce of d + 2 doubles.
+        Returns [d/d noise, d/d cov sigma, d/d cov beta...] (the reference's key order)."""
+        ops, t, n = self.ops, self.torch, self.n
+        nbeta = len(self.beta)
+        total = np.zeros(2 + nbeta)
+        if not hasattr(self, "slab"):
+            b = min(self.block, ((n + 127) // 128) * 128)
+            self.slab = ops.empty(n * (b + (b & 1)))
+        for k, k0, kb in self._blocks():
+            if owner_of(k, self.world) != self.rank:
+                continue
+            nk, lds = n - k0, kb + (kb & 1)
+            S = self.slab[: nk * lds].view(nk, lds)
+            S.zero_()
+            S[:kb, :kb].diagonal().fill_(1.0)
+            S = S[:, :kb]
+            Lsub = self.A[k0:n, k0:n]
+            dsub = self.dinv[(k0 // _lib.GPX_NB) * _lib.GPX_NB * _lib.GPX_NB:]
+            ops.trsm_left(0, Lsub, dsub, S)
+            ops.trsm_left(1, Lsub, dsub, S)
+            total += ops.grad_trace_slab(self.kind, self.sigma, self.beta, self.X, self.d, self.alpha, S, k0, k0)
+        tot = t.from_numpy(total).to(self.A.device)
+        tot = self._all_reduce(tot, self.dist.ReduceOp.SUM)
+        return tot.cpu().numpy()
 
     # ------------------------------------------------------------------ predict
     def predict(self, Xs):

@@ -133,6 +133,14 @@ int gpx_diag(gpx_handle* h, int n, const double* A, int lda, double* diag_out);
 int gpx_grad_trace(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
                    const double* beta_host, const double* alpha, const double* Kinv, int ldk,
                    double* out_host);
+/* The same sums restricted to a slab of the symmetric matrix: Kinv_slab holds rows
+ * [row_off, row_off+nrows) x columns [col_off, col_off+ncols) of Ky^-1 (only its entries on or below
+ * the global diagonal are read).  The slabs of a partition of the lower triangle add up to
+ * gpx_grad_trace's result (the sums are linear): this is how the block-column owners of the
+ * multi-GPU path each contribute their share of regression.py:62-75 without forming Ky^-1 whole. */
+int gpx_grad_trace_slab(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
+                        const double* beta_host, const double* alpha, const double* Kinv_slab, int ldk,
+                        int row_off, int col_off, int nrows, int ncols, double* out_host);
 
 /* ---- fused estimator paths ------------------------------------------------------------ */
 /* One evaluation of (LML, grad) = regression.py:46-76 from one Gram + one factorisation:

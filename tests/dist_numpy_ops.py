@@ -92,6 +92,28 @@ class NumpyOps:
         n, m = A.shape
         y.numpy()[:n] = A.numpy() @ x.numpy()[:m]
 
+    def grad_trace_slab(self, kind, sigma, beta, X, d, alpha, slab, row_off, col_off):
+        """Restatement of the slab sums: entries on/below the global diagonal, weight 2 off it."""
+        Xn = X.numpy()[:, :d]
+        al = alpha.numpy()
+        S = slab.numpy()
+        nr, nc = S.shape
+        rows, cols = np.arange(row_off, row_off + nr), np.arange(col_off, col_off + nc)
+        name = KIND_NAME[kind]
+        Kb = orc.cov(name, Xn[rows], Xn[cols], sigma, beta)[0]
+        A = np.outer(al[rows], al[cols]) - S
+        w = np.where(rows[:, None] > cols[None, :], 2.0, np.where(rows[:, None] == cols[None, :], 1.0, 0.0))
+        out = [0.5 * np.sum(np.where(rows[:, None] == cols[None, :], A, 0.0)), 0.5 * np.sum(w * A * Kb) / sigma]
+        beta = np.atleast_1d(np.asarray(beta, float))
+        if name == "rbf":
+            sq = ((Xn[rows][:, None, :] - Xn[cols][None, :, :]) ** 2).sum(-1)
+            out.append(0.5 * np.sum(w * A * Kb * (-0.5 * sq)))
+        else:
+            for k in range(d):
+                sq = (Xn[rows, k][:, None] - Xn[cols, k][None, :]) ** 2
+                out.append(0.5 * np.sum(w * A * Kb * (-0.5 * sq)))
+        return np.array(out)
+
     def sync(self):
         pass
 

@@ -61,6 +61,10 @@ def worker(rank, world, port, case, q):
         else:
             lml = gp.fit(X, y, kind, sigma, beta, noise)
             mean, cov = gp.predict(Xs)
+            g = gp.grad()
+            go, _ = orc.gpr_grad(kind, X, y, sigma, beta, noise, spd_inverse=True)
+            go = np.concatenate([go["sigma"], go["cov__sigma"], go["cov__beta"]])
+            out["grad"] = float(np.abs(g - go).max() / np.abs(go).max())
             L = np.tril(host(gp.A[:n, :n]))
             Lo = orc.gpr_factor(kind, X, sigma, beta, noise)
             lml_o, a_o, _ = orc.gpr_lml(kind, X, y, sigma, beta, noise, L=Lo)

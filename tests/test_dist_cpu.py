@@ -26,7 +26,7 @@ def test_world2_matches_oracle(case):
     for o in _run(2, case):
         assert o["shapes"] == ((case["m"],), (case["m"], case["m"]))
         assert o["L"] < 1e-12 and o["dinv"] < 1e-9, o
-        assert o["lml"] < 1e-11 and o["alpha"] < 1e-9, o
+        assert o["lml"] < 1e-11 and o["alpha"] < 1e-9 and o["grad"] < 1e-9, o
         assert o["mean"] < 1e-10 and o["cov"] < 1e-9 and o["res"] < 1e-10, o
 
 

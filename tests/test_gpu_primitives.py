@@ -268,3 +268,35 @@ def test_grad_trace_matches_oracle(rt, kind, d, n):
     got = np.array(list(out))
     ref = np.concatenate([g_o["sigma"], g_o["cov__sigma"], g_o["cov__beta"]])
     assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("kind,d,n,cuts", [("ard", 8, 300, [0, 128, 256, 300]), ("rbf", 2, 257, [0, 128, 256, 257]),
+                                           ("ard", 3, 200, [0, 64, 200])])
+def test_grad_trace_slabs_add_up(rt, kind, d, n, cuts):
+    """Block-column slabs of the lower triangle (rows from the slab's first column down, as the
+    multi-GPU owners hold them) sum to the whole-matrix gradient of regression.py:62-75."""
+    from gaussian_process_amd import _lib
+    rng = np.random.default_rng(n + 1)
+    X = rng.uniform(-3, 3, (n, d))
+    y = rng.standard_normal(n)
+    beta = rng.uniform(0.05, 1.0, d if kind == "ard" else 1)
+    sigma, noise = 0.9, 0.2
+    g_o, alpha = O.gpr_grad(kind, X, y, sigma, beta, noise)
+    K, _, _ = O.cov(kind, X, None, sigma, beta)
+    Kinv = np.linalg.inv(K + noise * np.eye(n))
+    dX, dal = up(rt, X), rt.upload_vector(alpha)
+    barr, bp = _lib.host_doubles(beta)
+    total = np.zeros(2 + len(barr))
+    for c0, c1 in zip(cuts[:-1], cuts[1:]):
+        slab = up(rt, Kinv[c0:, c0:c1])               # entries above the diagonal present but must be ignored
+        out = (C.c_double * (2 + len(barr)))()
+        ok(rt.lib.gpx_grad_trace_slab(rt.h, _lib.GPX_KIND[kind], P(dX), n, dX.shape[1], d, sigma, bp, P(dal),
+                                      P(slab), slab.shape[1], c0, c0, n - c0, c1 - c0,
+                                      C.cast(out, C.POINTER(C.c_double))))
+        total += np.array(list(out))
+    ref = np.concatenate([g_o["sigma"], g_o["cov__sigma"], g_o["cov__beta"]])
+    assert np.abs(total - ref).max() <= 1e-10 * np.abs(ref).max()
+    # a slab outside the matrix is rejected, not faulted
+    assert rt.lib.gpx_grad_trace_slab(rt.h, _lib.GPX_KIND[kind], P(dX), n, dX.shape[1], d, sigma, bp, P(dal),
+                                      P(slab), slab.shape[1], n - 10, 0, 64, 64,
+                                      C.cast(out, C.POINTER(C.c_double))) == -1
