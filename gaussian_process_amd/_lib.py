@@ -49,6 +49,7 @@ SIGNATURES = {
     "gpx_gpr_predict": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _dp, _i, _i,
                              _dp, _i, _dp, _dp, _dp, _i, _dp, _i]),
     "gpx_ep_scale": (_i, [C.c_void_p, _i, _dp, _i, _dp, _dp, _i, _dp, _i]),
+    "gpx_ep_sweep": (_i, [C.c_void_p, _i, _dp, _i, _dp, _dp, _dp, C.POINTER(C.c_int), _i, _dp]),
     "gpx_ep_recompute": (_i, [C.c_void_p, _i, _dp, _i, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp, _dp]),
 }
 

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpx.so")
-SOURCES = ["gemm_f64.hip", "leaf.hip", "gram.hip", "blas2.hip", "trsv.hip", "gpx_api.hip"]
+SOURCES = ["gemm_f64.hip", "leaf.hip", "gram.hip", "blas2.hip", "trsv.hip", "ep.hip", "gpx_api.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]

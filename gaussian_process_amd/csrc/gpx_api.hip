@@ -629,4 +629,16 @@ int gpx_ep_recompute(gpx_handle* h, int n, const double* K, int ldk, const doubl
   return info;
 }
 
+int gpx_ep_sweep(gpx_handle* h, int n, double* Sigma, int ld, const double* y, double* tau, double* nu,
+                 const int* order_host, int count, double* work) {
+  GPX_REQUIRE(h != nullptr && y && tau && nu && work, "ep_sweep: null argument");
+  GPX_REQUIRE(n > 0 && count >= 0 && (count == 0 || order_host != nullptr), "ep_sweep: bad n / count / order");
+  GPX_TRY(check_mat("ep_sweep: Sigma", Sigma, ld, n));
+  GPX_REQUIRE(gpx_aligned16(work), "ep_sweep: work must be 16-byte aligned");
+  if (count == 0) return 0;
+  DeviceGuard dg(h->device);
+  const size_t n_even = ((size_t)n + 1) & ~(size_t)1;
+  return gpx_ep_sweep_launch(h->stream, n, Sigma, ld, y, tau, nu, order_host, count, work, work + n_even);
+}
+
 }  // extern "C"

@@ -83,6 +83,10 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int n
 int gpx_trsv_launch(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv, double* x,
                     long incx, double* red, size_t red_elems);
 
+// ep.hip: one sweep of site updates in the given order; colbuf n doubles, scal 2 doubles (device)
+int gpx_ep_sweep_launch(hipStream_t s, int n, double* Sigma, long ld, const double* y, double* tau, double* nu,
+                        const int* order_host, int count, double* colbuf, double* scal);
+
 // blas2.hip
 int gpx_logdet_launch(hipStream_t s, int n, const double* L, long ldl, double* red, double* out_dev);
 int gpx_dot_launch(hipStream_t s, int n, const double* x, const double* y, double* red, double* out_dev);

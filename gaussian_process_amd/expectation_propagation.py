@@ -1,9 +1,11 @@
 """GP binary classification by expectation propagation, probit likelihood
 (reference: gaussian_process/expectation_propagation.py).
 
-Per the north star the scalar site-update loop (expectation_propagation.py:72-88) stays on the
-host; every Cholesky / triangular solve / V^T V around it runs on the MI355X through libgpx:
+Everything numerical runs on the MI355X through libgpx, including the sequential site-update
+loop: tau, nu, Sigma stay in HBM for the whole fit and only tau / nu (n doubles
+each) come back per sweep for the convergence test.
 
+  site-update sweep            expectation_propagation.py:72-88         -> gpx_ep_sweep
   init + per-sweep recompute   expectation_propagation.py:61-65, 90-94  -> gpx_ep_recompute
   w, z after convergence       expectation_propagation.py:107-108       -> gpx_gemv + gpx_trsm
   _posterior                   expectation_propagation.py:115-119       -> gpx_trsm (+ host sums)
@@ -17,7 +19,6 @@ expectation_propagation.py:70-71.
 import ctypes as C
 
 import numpy as np
-from scipy.linalg import blas as _blas
 from scipy.special import log_ndtr, ndtr
 from sklearn.base import ClassifierMixin
 from sklearn.utils import check_X_y
@@ -47,20 +48,24 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         self.fit(self.Xtr, self.ytr)
 
     # ------------------------------------------------------------------ device helpers
-    def _recompute(self, dv, tau, nu):
-        """L = chol(I + S K S), V = L^-1 S K, Sigma = K - V^T V, mu = Sigma nu on the GPU."""
+    def _recompute(self, dv):
+        """L = chol(I + S K S), V = L^-1 S K, Sigma = K - V^T V, mu = Sigma nu on the GPU, from the
+        tau / nu vectors resident on the device."""
         rt = dv["rt"]
         n = dv["n"]
-        dv["tau"][:n].copy_(rt.torch.from_numpy(tau))
-        dv["nu"][:n].copy_(rt.torch.from_numpy(nu))
         ld = dv["K"].shape[1]
         rc = rt.lib.gpx_ep_recompute(rt.h, n, ptr(dv["K"]), ld, ptr(dv["tau"]), ptr(dv["nu"]),
                                      ptr(dv["B"]), ptr(dv["V"]), ptr(dv["Sigma"]), ld, ptr(dv["dinv"]),
                                      ptr(dv["s"]), ptr(dv["mu"]))
         _lib.check(rc, "gpx_ep_recompute")
-        Sigma = np.ascontiguousarray(rt.download(dv["Sigma"][:n, :n]))
-        mu = rt.download(dv["mu"][:n]).copy()
-        return Sigma, mu
+
+    def _sweep(self, dv, order):
+        """One pass over the sites in `order` (expectation_propagation.py:72-88) on the device."""
+        rt = dv["rt"]
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        _lib.check(rt.lib.gpx_ep_sweep(rt.h, dv["n"], ptr(dv["Sigma"]), dv["Sigma"].shape[1], ptr(dv["y"]),
+                                       ptr(dv["tau"]), ptr(dv["nu"]), order.ctypes.data_as(C.POINTER(C.c_int)),
+                                       len(order), ptr(dv["work"])), "gpx_ep_sweep")
 
     def _solve_vec(self, dv, rhs, trans):
         """L^-1 rhs (trans=0) or L^-T rhs (trans=1) for a host vector, on the GPU."""
@@ -107,38 +112,24 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         rt = runtime()
         rt.bind_stream()
         dv = dict(rt=rt, n=n, K=rt.upload_matrix(K), B=rt.matrix(n, n), V=rt.matrix(n, n),
-                  Sigma=rt.matrix(n, n), dinv=rt.dinv(n), tau=rt.vector(n), nu=rt.vector(n),
-                  s=rt.vector(n), mu=rt.vector(n))
-        Sigma, mu = self._recompute(dv, tau, nu)
+                  Sigma=rt.matrix(n, n), dinv=rt.dinv(n), tau=rt.upload_vector(tau), nu=rt.upload_vector(nu),
+                  s=rt.vector(n), mu=rt.vector(n), y=rt.upload_vector(y), work=rt.vector(n + 4))
+        self._recompute(dv)
 
         order = np.arange(n)
         for sweep in range(100):
-            tau_prev = tau.copy()
-            nu_prev = nu.copy()
+            tau_prev = tau
+            nu_prev = nu
             if shuffle:
                 order = np.random.permutation(n)
-            SigmaT = Sigma.T  # same symmetric matrix, Fortran-ordered view for the in-place dger
-            for i in order:
-                if frozen[i]:
-                    continue
-                sii = Sigma[i, i]
-                tau_cav = 1.0 / sii - tau[i]
-                nu_cav = mu[i] / sii - nu[i]
-                dom = tau_cav ** 2 + tau_cav
-                rdom = np.sqrt(dom)
-                z = y[i] * nu_cav / rdom
-                ratio = np.exp(-0.5 * z * z - _HALF_LOG_2PI - log_ndtr(z))
-                mu_hat = nu_cav / tau_cav + y[i] * ratio / rdom
-                var_hat = 1.0 / tau_cav - ratio / dom * (z + ratio)
-                dtau = 1.0 / var_hat - tau_cav - tau[i]
-                tau[i] += dtau
-                nu[i] = mu_hat / var_hat - nu_cav
-                col = Sigma[i].copy()
-                _blas.dger(-dtau / (1.0 + dtau * sii), col, col, a=SigmaT, overwrite_a=1)
-                mu = Sigma @ nu
-            Sigma, mu = self._recompute(dv, tau, nu)
+            self._sweep(dv, order[~frozen[order]])
+            self._recompute(dv)
+            tau = rt.download(dv["tau"][:n]).copy()
+            nu = rt.download(dv["nu"][:n]).copy()
             if np.sum((tau_prev - tau) ** 2) < eps and np.sum((nu_prev - nu) ** 2) < eps:
                 break
+        Sigma = np.ascontiguousarray(rt.download(dv["Sigma"][:n, :n]))
+        mu = rt.download(dv["mu"][:n]).copy()
 
         self.nu_tilde = nu
         self.tau_tilde = tau

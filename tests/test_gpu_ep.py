@@ -1,4 +1,4 @@
-"""GPU parity of the EP classifier (host site loop + GPU Cholesky/solves) against fixtures made by
+"""GPU parity of the EP classifier (site loop, Cholesky and solves all on the device) against fixtures made by
 the real reference with _ep(K, shuffle=False) (expectation_propagation.py:25-108)."""
 import numpy as np
 import pytest
@@ -45,3 +45,38 @@ def test_ep_notebook_fit_score():
     ep.fit(g["Xtr"], g["ytr"])
     assert abs(ep.score(g["Xte"], g["yte"]) - 0.92) < 1e-12
     assert abs(ep.log_marginal_likelihood() - float(g["lml"])) < 1e-4
+
+
+@pytest.mark.parametrize("n", [37, 200, 515])
+def test_ep_sweep_matches_oracle_site_by_site(n):
+    """gpx_ep_sweep (site loop on the device) against the oracle's sequential
+    ep_site_update over one shuffled sweep with some sites skipped: tau, nu and Sigma afterwards."""
+    import ctypes as C
+    from gaussian_process_amd import _lib
+    from gaussian_process_amd.device import ptr, runtime
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-2, 2, (n, 2))
+    y = np.sign(X[:, 0] * X[:, 1] + 0.1 * rng.standard_normal(n))
+    K = O.cov("rbf", X, None, 1.0, 1.0)[0] + 1e-8 * np.eye(n)
+    tau0 = rng.uniform(0.0, 0.5, n)
+    nu0 = rng.standard_normal(n) * 0.1
+    _, Sigma, mu, _ = O.ep_recompute(K, tau0, nu0)
+    order = rng.permutation(n)[: max(1, (3 * n) // 4)]
+    tau, nu, Sg, m = tau0.copy(), nu0.copy(), Sigma.copy(), mu.copy()
+    for i in order:
+        O.ep_site_update(int(i), y[i], Sg, m, tau, nu)
+    rt = runtime()
+    rt.bind_stream()
+    dS, dy, dt, dn, work = rt.upload_matrix(Sigma), rt.upload_vector(y), rt.upload_vector(tau0), \
+        rt.upload_vector(nu0), rt.vector(n + 4)
+    o32 = np.ascontiguousarray(order, dtype=np.int32)
+    _lib.check(rt.lib.gpx_ep_sweep(rt.h, n, ptr(dS), dS.shape[1], ptr(dy), ptr(dt), ptr(dn),
+                                   o32.ctypes.data_as(C.POINTER(C.c_int)), len(o32), ptr(work)), "gpx_ep_sweep")
+    assert relerr(rt.download(dt[:n]), tau) < 1e-10
+    assert relerr(rt.download(dn[:n]), nu) < 1e-10
+    assert relerr(rt.download(dS[:n, :n]), Sg) < 1e-10
+    # bad site index is rejected before anything is launched for it
+    bad = np.array([n], dtype=np.int32)
+    assert rt.lib.gpx_ep_sweep(rt.h, n, ptr(dS), dS.shape[1], ptr(dy), ptr(dt), ptr(dn),
+                               bad.ctypes.data_as(C.POINTER(C.c_int)), 1, ptr(work)) == -1
