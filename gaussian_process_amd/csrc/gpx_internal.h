@@ -61,7 +61,7 @@ struct GemmDesc {
 
 int gpx_gemm_launch(hipStream_t s, const GemmDesc& g);
 
-// leaf kernels (leaf.hip)
+// leaf kernels (leaf.hip: 128x128 diagonal block Cholesky + inverse on the matrix cores)
 int gpx_leaf_potf2_inv(hipStream_t s, int nb, double* A, long lda, double* dinv_blk, int* info_dev,
                        int global_off);
 int gpx_leaf_diag_inv_batched(hipStream_t s, int n, const double* L, long ldl, double* dinv);
