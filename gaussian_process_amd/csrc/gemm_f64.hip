@@ -25,6 +25,8 @@
 // Triangular operands (a_tri / b_tri: the STORED matrix is lower triangular and starts on its
 // diagonal) restrict the k range per tile and zero-mask inside the boundary tile, so blocks that
 // lie strictly above the diagonal are never read (they may hold anything, including NaN).
+#include <cstdlib>
+
 #include "gpx_internal.h"
 
 
@@ -146,6 +148,19 @@ struct Tile {
 __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower, unsigned nsuper, int& bi,
                                              int& bj) {
   const unsigned bid = blockIdx.x;
+  if (nsuper == 0) {  // small launch: one block per tile, linear (row-major / packed lower) order
+    if (lower) {
+      unsigned r = (unsigned)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= bid) ++r;
+      while (r * (r + 1) / 2 > bid) --r;
+      bi = (int)r;
+      bj = (int)(bid - r * (r + 1) / 2);
+    } else {
+      bi = (int)(bid / (unsigned)tiles_n);
+      bj = (int)(bid % (unsigned)tiles_n);
+    }
+    return bi < tiles_m && bj < tiles_n;
+  }
   const unsigned xcd = bid & 7, idx = bid >> 3;
   const unsigned st = (idx >> 6) * 8 + xcd, within = idx & 63;
   if (st >= nsuper) return false;
@@ -356,6 +371,14 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     nsuper = (unsigned)((tm + 7) / 8) * (unsigned)((tn + 7) / 8);
   }
   dim3 grid(((nsuper + 7) / 8) * 8 * 64), block(NTHREADS);
+  // Launches that cannot fill the chip anyway (at most two workgroups per CU) skip the XCD
+  // super-tile mapping: one block per tile, so the dispatcher spreads them over all XCDs and CUs
+  // instead of packing the few live blocks of a sparse grid onto a handful of CUs.
+  const long ntiles = g.c_lower ? (long)max(tm, tn) * (max(tm, tn) + 1) / 2 : (long)tm * tn;
+  if (ntiles <= 512) {
+    nsuper = 0;
+    grid = dim3((unsigned)ntiles);
+  }
   if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
     hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
   else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
@@ -384,6 +407,14 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   // 128 x 128 tiles unless that leaves most of the 256 CUs (2 workgroups each) idle.  In-place
   // launches (D aliases an operand) rely on one workgroup owning a whole operand panel: 128 only.
   const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.c_lower ? 2 : 1);
+  static const bool log_shapes = getenv("GPX_GEMM_LOG") != nullptr;   // development: one line per launch
+  if (log_shapes)
+    fprintf(stderr, "GEMMLOG %d %d %d lower=%d atri=%d btri=%d inplace=%d cfg=%d\n", g.M, g.N, g.K, g.c_lower,
+            g.a_tri, g.b_tri, g.inplace, (g.inplace == GPX_INPLACE_A && g.M <= 16384) ? 1 : (g.inplace || big_tiles >= 384) ? 4 : 2);
+  // In-place right-multiplies (D aliases A, N <= 128) with few rows: 32-row tiles, still 128 wide, so
+  // that a 128 x 128 x 128 leaf solve is spread over 4 CUs instead of being one CU's 13.7 us of MFMA
+  // time.  (When D aliases B the workgroup must own all K = M <= 128 rows: 128-row tiles only.)
+  if (g.inplace == GPX_INPLACE_A && g.M <= 16384) return launch_cfg<1, 4>(s, g);
   if (g.inplace || big_tiles >= 384) return launch_cfg<4, 4>(s, g);
   return launch_cfg<2, 2>(s, g);
 }

@@ -52,7 +52,7 @@ int trsm_rlt(hipStream_t s, int M, int n, const double* L, long ldl, const doubl
   if (n <= NB) {
     // X <- X * dinv^T : in-place safe, each workgroup reads exactly the rows x 128 cols it writes
     GemmDesc g = mk(X, ldx, GPX_LAY_KC, dinv, NB, GPX_LAY_KC, nullptr, 0, X, ldx, M, n, n, 1.0, 0.0);
-    g.inplace = 1;
+    g.inplace = GPX_INPLACE_A;
     return gpx_gemm_launch(s, g);
   }
   const int n1 = split_point(n), n2 = n - n1;
@@ -71,7 +71,7 @@ int trsm_lln(hipStream_t s, int n, int m, const double* L, long ldl, const doubl
   if (n <= 0 || m <= 0) return 0;
   if (n <= NB) {
     GemmDesc g = mk(dinv, NB, GPX_LAY_KC, B, ldb, GPX_LAY_RC, nullptr, 0, B, ldb, n, m, n, 1.0, 0.0);
-    g.inplace = 1;
+    g.inplace = GPX_INPLACE_B;
     return gpx_gemm_launch(s, g);
   }
   const int n1 = split_point(n), n2 = n - n1;
@@ -91,7 +91,7 @@ int trsm_ltn(hipStream_t s, int n, int m, const double* L, long ldl, const doubl
   if (n <= NB) {
     // B <- dinv^T B : op(A) = dinv^T is stored [k][m] = dinv itself (RC)
     GemmDesc g = mk(dinv, NB, GPX_LAY_RC, B, ldb, GPX_LAY_RC, nullptr, 0, B, ldb, n, m, n, 1.0, 0.0);
-    g.inplace = 1;
+    g.inplace = GPX_INPLACE_B;
     return gpx_gemm_launch(s, g);
   }
   const int n1 = split_point(n), n2 = n - n1;

@@ -46,6 +46,7 @@ static inline bool gpx_aligned16(const void* p) { return (reinterpret_cast<uintp
 // op(A) is M x K.  KC: stored [M][K] (k contiguous).  RC: stored [K][M] (rows of op contiguous).
 // op(B) is K x N.  KC: stored [N][K] (k contiguous).  RC: stored [K][N].
 enum { GPX_LAY_KC = 0, GPX_LAY_RC = 1 };
+enum { GPX_INPLACE_NONE = 0, GPX_INPLACE_A = 1, GPX_INPLACE_B = 2 };
 
 struct GemmDesc {
   const double* A; long lda; int a_lay; int a_tri;  // a_tri: stored matrix is lower (row >= col valid)
@@ -56,7 +57,8 @@ struct GemmDesc {
   double alpha, beta;
   int c_lower;       // write only row >= col (D starts on the diagonal)
   double diag_add;   // added to D[i][i]
-  int inplace;       // D aliases A or B (leaf solves): one workgroup must own the whole panel
+  int inplace;       // GPX_INPLACE_A: D aliases A (N <= 128, row tiles independent); GPX_INPLACE_B: D aliases B
+                     // (M <= 128, column tiles independent); one workgroup owns the whole operand panel
 };
 
 int gpx_gemm_launch(hipStream_t s, const GemmDesc& g);
