@@ -171,9 +171,12 @@ __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower
     while (sr * (sr + 1) / 2 > st) --sr;
     sc = st - sr * (sr + 1) / 2;
   } else {
+    // skewed columns: with stc a multiple of 8, plain st % stc would hand XCD x the same super-tile
+    // columns on every row; when the work per tile depends on the column (triangular B operand)
+    // that unbalances the XCDs by up to 1.5x.  The skew walks every XCD through all columns.
     const unsigned stc = (tiles_n + 7) / 8;
     sr = st / stc;
-    sc = st % stc;
+    sc = (st % stc + sr) % stc;
   }
   bi = (int)(sr * 8 + (within >> 3));
   bj = (int)(sc * 8 + (within & 7));

@@ -2,7 +2,12 @@
 efficiency by size class."""
 import csv, sys, collections
 d = sys.argv[1]
-shapes = [l.split() for l in open(d + "/gemmlog.txt")]
+shapes, phase_of, phase = [], [], "potrf"
+for l in open(d + "/gemmlog.txt"):
+    if l.startswith("PHASE"):
+        phase = l.split()[1]
+    elif l.startswith("GEMMLOG"):
+        shapes.append(l.split()); phase_of.append(phase)
 rows = list(csv.DictReader(open(d + "/pt_kernel_trace.csv")))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
@@ -13,13 +18,13 @@ leaf = [r for r in rows[gi + 1:] if "leaf" in r["Kernel_Name"]]
 print("gemm launches in trace %d, in log %d; leaves %d" % (len(gem), len(shapes), len(leaf)))
 cls = collections.OrderedDict()
 tot_t = tot_f = 0.0
-for r, s in zip(gem, shapes):
+for r, s, ph in zip(gem, shapes, phase_of):
     M, N, K = int(s[1]), int(s[2]), int(s[3])
     lower = int(s[4].split("=")[1]); atri = int(s[5].split("=")[1]); btri = int(s[6].split("=")[1])
     fl = 2.0 * M * N * K * (0.5 if lower else 1.0) * (0.5 if (atri or btri) else 1.0)
     t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
     key = "K<=128" if K <= 128 else "K<=512" if K <= 512 else "K<=2048" if K <= 2048 else "K<=8192" if K <= 8192 else "K>8192"
-    key += " " + s[8]
+    key = ph + " " + key + " " + s[8]
     c = cls.setdefault(key, [0, 0.0, 0.0])
     c[0] += 1; c[1] += t; c[2] += fl
     tot_t += t; tot_f += fl
