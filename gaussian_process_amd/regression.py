@@ -112,14 +112,22 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         return dv["rt"].download(dv["alpha"][: self.n])
 
     def predict(self, X):
-        return self.predict_with_variance(X)[0]
+        """Predictive mean (regression.py:28-29).  Only the mean is returned, so the m x m covariance
+        the reference builds and discards is never formed, and the test points are streamed through
+        the device in batches."""
+        return self.predict_with_variance(X, full_cov=False)[0]
 
-    def predict_with_variance(self, X, full_cov=True):
+    def predict_with_variance(self, X, full_cov=True, batch=16384):
         """(mean (m,), cov (m, m)) as regression.py:31-44; ``full_cov=False`` returns the
-        diagonal variance (m,) instead and never forms the m x m matrix."""
+        diagonal variance (m,) instead, never forms the m x m matrix and tiles over the test points
+        ``batch`` at a time (device memory n x batch, any m)."""
         X = np.ascontiguousarray(np.asarray(X), dtype=np.float64)
         assert X.ndim == 2 and X.shape[1] == self.dim
         m = X.shape[0]
+        if not full_cov and m > batch:
+            parts = [self.predict_with_variance(X[i:i + batch], full_cov=False, batch=batch)
+                     for i in range(0, m, batch)]
+            return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         st = self._evaluate(need_grad=False)
         if not st["has_factor"]:   # the gradient pass overwrote L with L^-1: factor again
             self._state = None
