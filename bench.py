@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--ntest", "--m", dest="m", type=int, default=4096)
     ap.add_argument("--cpu-n", type=int, default=8192)
     ap.add_argument("--block", type=int, default=0,
-                    help="block-column width of the multi-GPU Cholesky (0: 2048 on 1 rank, 1024 on more)")
+                    help="block-column width of the multi-GPU Cholesky (0: 2048 on 1-2 ranks, 1024 on 4, 512 on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -37,7 +37,7 @@ def main(args, rank, local_rank, world):
     from oracle import gp_oracle as O               # input generator only
     n, m, d = args.n, args.m, 8
     X, y, Xs, beta = O.synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
-    gp = DistributedGP(GpuOps(rt), dist, rank, world, block=getattr(args, "block", 0) or (2048 if world == 1 else 1024))
+    gp = DistributedGP(GpuOps(rt), dist, rank, world, block=getattr(args, "block", 0) or {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024))
     sigma, noise = 1.0, 0.1
 
     def step(marks):

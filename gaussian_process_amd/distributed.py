@@ -107,6 +107,29 @@ class GpuOps:
                                                 C.cast(out, C.POINTER(C.c_double))), "gpx_grad_trace_slab")
         return np.array(list(out))
 
+    # ---- a second stream for work that should overlap the main stream (the diagonal-block potrf of
+    # the look-ahead panel is a chain of one-workgroup kernels; the column update fills the other CUs)
+    def side_begin(self):
+        t = self.torch
+        if not hasattr(self, "_side"):
+            self._side = t.cuda.Stream(device=self.device)
+        ev = t.cuda.Event()
+        ev.record(t.cuda.current_stream(self.device))
+        self._side.wait_event(ev)
+        _lib.check(self.lib.gpx_set_stream(self.h, C.c_void_p(self._side.cuda_stream)), "gpx_set_stream")
+
+    def side_end(self):
+        """Back to the main stream; returns a token for side_join()."""
+        t = self.torch
+        ev = t.cuda.Event()
+        ev.record(self._side)
+        _lib.check(self.lib.gpx_set_stream(self.h, C.c_void_p(t.cuda.current_stream(self.device).cuda_stream)),
+                   "gpx_set_stream")
+        return ev
+
+    def side_join(self, ev):
+        self.torch.cuda.current_stream(self.device).wait_event(ev)
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -114,10 +137,11 @@ class GpuOps:
 class DistributedGP:
     """Exact GP regression over the ranks of a torch.distributed process group."""
 
-    def __init__(self, ops, dist, rank, world, block=2048, group=None):
+    def __init__(self, ops, dist, rank, world, block=2048, group=None, update_k=2048):
         assert block % _lib.GPX_NB == 0, "block must be a multiple of 128"
         self.ops, self.dist, self.rank, self.world, self.block, self.group = ops, dist, rank, world, block, group
         self.torch = ops.torch
+        self.update_k = update_k          # K the delayed trailing updates aim for (see potrf)
         self._gloo = dist.get_backend(group) == "gloo"
         self.n = 0
 
@@ -207,14 +231,28 @@ class DistributedGP:
             self.ops.gram(self.kind, self.sigma, self.beta, Xv[k0:], Xv[k0:k0 + kb],
                           self.A[k0:self.n, k0:k0 + kb], self.noise)
 
-    def _factor_panel(self, k, k0, kb, stg):
-        """Owner side of step k: potrf of the diagonal block, TRSM of the rows below, pack."""
-        n = self.n
+    def _factor_panel(self, k, k0, kb, stg, Pprev=None, kprev0=0):
+        """Owner side of step k: (look-ahead: first bring the column up to date with panel k-1,
+        given as Pprev,) potrf of the diagonal block, TRSM of the rows below, pack.  With a previous
+        panel the diagonal block is updated first and factored on the side stream while the main
+        stream updates the rows below it."""
+        n, ops = self.n, self.ops
         Akk = self.A[k0:k0 + kb, k0:k0 + kb]
         dk = self._dinv_slice(k0, kb)
-        self.ops.potrf_async(Akk, dk, self.info, k0)
+        if Pprev is None:
+            ops.potrf_async(Akk, dk, self.info, k0)
+        else:
+            top = Pprev[k0 - kprev0: k0 - kprev0 + kb]
+            ops.gemm(0, 1, kb, kb, Pprev.shape[1], -1.0, top, top, 1.0, Akk)
+            ops.side_begin()
+            ops.potrf_async(Akk, dk, self.info, k0)
+            token = ops.side_end()
+            if k0 + kb < n:
+                ops.gemm(0, 1, n - k0 - kb, kb, Pprev.shape[1], -1.0, Pprev[k0 - kprev0 + kb:], top, 1.0,
+                         self.A[k0 + kb:n, k0:k0 + kb])
+            ops.side_join(token)
         if k0 + kb < n:
-            self.ops.trsm_right(self.A[k0 + kb:n, k0:k0 + kb], Akk, dk)
+            ops.trsm_right(self.A[k0 + kb:n, k0:k0 + kb], Akk, dk)
         nk = n - k0
         stg[: nk * kb].view(nk, kb).copy_(self.A[k0:n, k0:k0 + kb])
         stg[nk * kb: nk * kb + dk.numel()].copy_(dk)
@@ -222,18 +260,28 @@ class DistributedGP:
     def _panel_len(self, k0, kb):
         return (self.n - k0) * kb + self._dinv_slice(k0, kb).numel()
 
-    def _update_column(self, j0, jb, Pk, k0):
-        """A[j0:, j0:j0+jb] -= P[j0-k0:, :] P[j0-k0 : j0-k0+jb, :]^T  (panel k given as Pk)."""
+    def _apply_filed(self, j0, jb, c0, c1):
+        """A[j0:, J] -= A[j0:, c0:c1] A[J, c0:c1]^T: the panels filed in columns [c0, c1) applied to
+        block column J = [j0, j0+jb) in ONE GEMM with K = c1 - c0."""
+        if c1 <= c0:
+            return
         n = self.n
-        rows = Pk[j0 - k0:]
-        self.ops.gemm(0, 1, n - j0, jb, Pk.shape[1], -1.0, rows, Pk[j0 - k0: j0 - k0 + jb], 1.0,
+        self.ops.gemm(0, 1, n - j0, jb, c1 - c0, -1.0, self.A[j0:n, c0:c1], self.A[j0:j0 + jb, c0:c1], 1.0,
                       self.A[j0:n, j0:j0 + jb])
 
     def potrf(self):
+        """Distributed right-looking Cholesky with DELAYED trailing updates.  Every rank files every
+        panel into its own buffer, so the panels a block column still has to absorb sit side by side
+        in A and are applied together: one GEMM with K = (number of pending panels) x block instead
+        of one short-K GEMM per panel (K = block is 15-20 % slower on the MFMA kernel and rewrites
+        the column every step).  A column is forced up to date one step before it becomes the
+        look-ahead column, so the critical chain only ever applies the newest panel."""
         ops, t, n, b = self.ops, self.torch, self.n, self.block
         blocks = self._blocks()
         stg = self.stg
         self.info.zero_()
+        group = max(1, self.update_k // b)                # panels per delayed update
+        applied = {j: 0 for j, _, _ in blocks}            # first panel column NOT yet applied to column j
         k, k0, kb = blocks[0]
         if owner_of(0, self.world) == self.rank:
             self._factor_panel(0, k0, kb, stg[0])
@@ -244,22 +292,25 @@ class DistributedGP:
             nk = n - k0
             Pk = cur[: nk * kb].view(nk, kb)
             mine = owner_of(k, self.world) == self.rank
-            done_ahead = -1
             if k + 1 < len(blocks):
                 k1, k10, k1b = blocks[k + 1]
                 o1 = owner_of(k1, self.world)
                 if o1 == self.rank:  # look-ahead: bring panel k+1 up to date, factor it, send it
-                    self._update_column(k10, k1b, Pk, k0)
-                    self._factor_panel(k1, k10, k1b, stg[k1 % 2])
-                    done_ahead = k1
+                    self._apply_filed(k10, k1b, applied[k1], k0)      # older panels (normally none)
+                    self._factor_panel(k1, k10, k1b, stg[k1 % 2], Pk, k0)
+                    applied[k1] = k0 + kb
                 work = self._bcast(stg[k1 % 2][: self._panel_len(k10, k1b)], o1, async_op=True)
             if not mine:  # file panel k (and its diagonal inverses) so every rank ends with all of L
                 self.A[k0:n, k0:k0 + kb].copy_(Pk)
                 dk = self._dinv_slice(k0, kb)
                 dk.copy_(cur[nk * kb: nk * kb + dk.numel()])
-            for j, j0, jb in blocks[k + 1:]:
-                if owner_of(j, self.world) == self.rank and j != done_ahead:
-                    self._update_column(j0, jb, Pk, k0)
+            for j, j0, jb in blocks[k + 2:]:
+                if owner_of(j, self.world) != self.rank:
+                    continue
+                pending = (k0 + kb - applied[j] + b - 1) // b
+                if j == k + 2 or pending >= group:
+                    self._apply_filed(j0, jb, applied[j], k0 + kb)
+                    applied[j] = k0 + kb
         # LAPACK info: smallest failing leading minor over all ranks (0 = success)
         big = 2 ** 30
         loc = int(self.info[0].item())

@@ -114,6 +114,15 @@ class NumpyOps:
                 out.append(0.5 * np.sum(w * A * Kb * (-0.5 * sq)))
         return np.array(out)
 
+    def side_begin(self):
+        pass
+
+    def side_end(self):
+        return None
+
+    def side_join(self, token):
+        pass
+
     def sync(self):
         pass
 
