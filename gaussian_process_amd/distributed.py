@@ -137,11 +137,12 @@ class GpuOps:
 class DistributedGP:
     """Exact GP regression over the ranks of a torch.distributed process group."""
 
-    def __init__(self, ops, dist, rank, world, block=2048, group=None, update_k=2048):
+    def __init__(self, ops, dist, rank, world, block=2048, group=None, update_k=2048, grad_block=None):
         assert block % _lib.GPX_NB == 0, "block must be a multiple of 128"
         self.ops, self.dist, self.rank, self.world, self.block, self.group = ops, dist, rank, world, block, group
         self.torch = ops.torch
         self.update_k = update_k          # K the delayed trailing updates aim for (see potrf)
+        self.grad_block = grad_block or (2048 if world <= 2 else 1024)   # column width of the gradient's own partition
         self._gloo = dist.get_backend(group) == "gloo"
         self.n = 0
 
@@ -345,12 +346,19 @@ class DistributedGP:
         ops, t, n = self.ops, self.torch, self.n
         nbeta = len(self.beta)
         total = np.zeros(2 + nbeta)
-        if not hasattr(self, "slab"):
-            b = min(self.block, ((n + 127) // 128) * 128)
-            self.slab = ops.empty(n * (b + (b & 1)))
-        for k, k0, kb in self._blocks():
-            if owner_of(k, self.world) != self.rank:
+        # The gradient has its own column partition (every rank holds all of L, so any partition
+        # works): wide blocks for GEMM efficiency, dealt in snake order (r, 2P-1-r, 2P+r, ...) because
+        # the cost of a block falls like (n - j0)^2 and plain cyclic dealing would load rank 0 twice
+        # as heavily as the last rank.
+        gb = min(self.grad_block, ((n + 127) // 128) * 128)
+        if getattr(self, "slab", None) is None or self.slab.numel() < n * gb:
+            self.slab = ops.empty(n * gb)
+        nblk = (n + gb - 1) // gb
+        for k in range(nblk):
+            pos = k % (2 * self.world)
+            if (pos if pos < self.world else 2 * self.world - 1 - pos) != self.rank:
                 continue
+            k0, kb = k * gb, min(gb, n - k * gb)
             nk, lds = n - k0, kb + (kb & 1)
             S = self.slab[: nk * lds].view(nk, lds)
             S.zero_()

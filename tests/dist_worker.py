@@ -49,7 +49,8 @@ def worker(rank, world, port, case, q):
             from dist_numpy_ops import NumpyOps
             ops = NumpyOps()
         host = lambda x: x.detach().cpu().numpy()
-        gp = DistributedGP(ops, dist, rank, world, block=block, update_k=case.get("update_k", 2048))
+        gp = DistributedGP(ops, dist, rank, world, block=block, update_k=case.get("update_k", 2048),
+                           grad_block=case.get("grad_block", 256))
         out = {"rank": rank}
         if case.get("expect_fail"):
             try:
