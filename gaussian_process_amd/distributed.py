@@ -194,8 +194,7 @@ class DistributedGP:
         ops, t = self.ops, self.torch
         n, d = X.shape
         self.n, self.d = n, d
-        self.kind, self.sigma, self.noise = _lib.GPX_KIND[kind], float(sigma), float(noise)
-        self.beta = np.asarray(beta, dtype=np.float64).reshape(-1)
+        self.set_theta(kind, sigma, beta, noise)
         ld = max(32, ((n + 31) // 32) * 32)
         self.A = ops.empty(n, ld)
         self.X = ops.zeros(n, max(32, ((d + 31) // 32) * 32))
@@ -208,6 +207,15 @@ class DistributedGP:
         cap = n * b + ((b + 127) // 128) * 128 * 128
         self.stg = [ops.empty(cap), ops.empty(cap)]     # double-buffered panel staging
         self.rhs = ops.zeros(n, 2)
+
+    def set_theta(self, kind, sigma, beta, noise):
+        """Hyper-parameters of the next build_gram(): kernel kind ("rbf" / "ard" or the C ABI's id),
+        kernel amplitude, beta (1 value for RBF, d for ARD), noise variance."""
+        self.kind = _lib.GPX_KIND[kind] if isinstance(kind, str) else int(kind)
+        self.sigma, self.noise = float(sigma), float(noise)
+        self.beta = np.asarray(beta, dtype=np.float64).reshape(-1)
+        if self.kind == _lib.GPX_KIND["rbf"]:
+            self.beta = self.beta[:1]
 
     def upload_test(self, Xs):
         t = self.torch

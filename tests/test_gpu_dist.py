@@ -40,3 +40,16 @@ def test_world2_gpu_not_positive_definite():
     assert outs[0]["info"] > 0 and outs[0]["info"] == outs[1]["info"]
     for o in outs:
         assert o["raised"] is not None and "not positive definite" in o["raised"]
+
+
+def test_world2_estimator_interface_and_empirical_bayes():
+    """DistributedGaussianProcessRegression: the reference's estimator API (regression.py:8-76,
+    base.py:21-58) over two ranks -- values against the oracle, identical optimiser path on both."""
+    case = dict(n=500, m=21, d=2, block=128, kind="ard", estimator=True, gpu=True)
+    outs = _run(2, case)
+    for o in outs:
+        assert o["keys"] == ["sigma", "cov__sigma", "cov__beta"]
+        assert o["lml"] < 1e-11 and o["alpha"] < 1e-9 and o["grad"] < 1e-8, o
+        assert o["mean"] < 1e-9 and o["cov"] < 1e-9 and o["mean_only"] < 1e-9, o
+        assert o["eb_gain"] > 0.0 and o["score"] > 0.5, o
+    assert outs[0]["theta"] == outs[1]["theta"]          # the ranks stayed in lockstep, bit for bit
