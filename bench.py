@@ -198,7 +198,7 @@ def main():
     torch.cuda.set_device(0)
     from gaussian_process_amd import _lib
     from gaussian_process_amd.device import runtime
-    from oracle import gp_oracle as O     # input generator + cpu_baseline only
+    from gaussian_process_amd.datasets import synthetic_ard
     rt = runtime(0)
     rt.bind_stream()
     lib = rt.lib
@@ -207,7 +207,7 @@ def main():
     def check(rc, what):
         _lib.check(rc, what)
 
-    X, y, Xs, beta = O.synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
+    X, y, Xs, beta = synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
     cfg = dict(n=n, m=m, d=d, beta=beta, sigma=1.0, noise=0.1)
     bufs = dict(X=rt.upload_matrix(X), y=rt.upload_vector(y), Xs=rt.upload_matrix(Xs),
                 Ky=rt.matrix(n, n), Kinv=rt.matrix(n, n), dinv=rt.dinv(n), V=rt.matrix(n, m),

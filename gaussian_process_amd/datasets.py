@@ -43,3 +43,20 @@ def generate_gp(n_samples=50, n_features=1, noise=0.01, range=(-3, 3),
     if return_latent:
         return X, y, z
     return X, y
+
+
+def synthetic_ard(n, m=256, d=8, seed=0, noise=0.1, n_features=2048):
+    """The benchmark workload of SURVEY.md section 8(d): X ~ U[-3, 3]^d (the reference's own range,
+    datasets.py:6,10), true ARD beta* = 0.5 * logspace(-2, 0, d), y = a random-Fourier-feature draw
+    from that GP (O(n); the reference's multivariate_normal is O(n^3)) + N(0, noise).  Host NumPy:
+    it only makes inputs.  Returns (X, y, Xs, beta*)."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-3.0, 3.0, size=(n, d))
+    Xs = rng.uniform(-3.0, 3.0, size=(m, d))
+    beta = 0.5 * np.logspace(-2.0, 0.0, d)
+    W = rng.standard_normal((d, n_features)) * np.sqrt(beta)[:, None]
+    b = rng.uniform(0.0, 2.0 * np.pi, size=n_features)
+    w = rng.standard_normal(n_features)
+    f = np.sqrt(2.0 / n_features) * (np.cos(X @ W + b) @ w)
+    y = f + np.sqrt(noise) * rng.standard_normal(n)
+    return X, y, Xs, beta

@@ -32,11 +32,9 @@ def main(args, rank, local_rank, world):
     rt = runtime(dev_index)
     rt.bind_stream()
     # synthetic inputs: the generator is deterministic, so every rank builds the same data
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from oracle import gp_oracle as O               # input generator only
+    from .datasets import synthetic_ard
     n, m, d = args.n, args.m, 8
-    X, y, Xs, beta = O.synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
+    X, y, Xs, beta = synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
     gp = DistributedGP(GpuOps(rt), dist, rank, world, block=getattr(args, "block", 0) or {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024))
     sigma, noise = 1.0, 0.1
 

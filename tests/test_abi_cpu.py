@@ -78,3 +78,24 @@ def test_no_cpu_fallback_without_gpu():
     from gaussian_process_amd import RBF
     with pytest.raises(_lib.GpxError):
         RBF()(np.zeros((3, 1)))
+
+
+def test_workload_generator_matches_the_oracles():
+    """bench.py draws its inputs from the package (the product path must not import the oracle);
+    the oracle keeps its own copy for the tests: both must produce the same workload."""
+    import numpy as np
+    from gaussian_process_amd.datasets import synthetic_ard
+    from oracle import gp_oracle as O
+    for a, b in zip(synthetic_ard(300, m=17, d=8, seed=3), O.synthetic_ard(300, m=17, d=8, seed=3)):
+        assert np.array_equal(a, b)
+
+
+def test_product_code_never_imports_the_oracle():
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussian_process_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
