@@ -7,8 +7,10 @@
 // (expectation_propagation.py:90-94) refreshes Sigma and mu from K, so here mu[i] = Sigma[i,:] . nu
 // is evaluated on demand while row i is being copied: per site
 //   site kernel   (1 workgroup)   row i -> colbuf, mu_i, the scalar moment match, tau[i], nu[i], coef
-//   rank-1 kernel (n/8 workgroups) Sigma[r][:] += coef * colbuf[r] * colbuf[:]      2 * 8 n^2 bytes
-// HBM-bound: 16 n^2 bytes per site (1.07 GB at n = 8192), nothing crosses to the host.
+//   rank-1 kernel (n/8 workgroups) Sigma[r][:r] += coef * colbuf[r] * colbuf[:r]    2 * 4 n^2 bytes
+// Sigma is symmetric: only its LOWER triangle is read and kept up to date during a sweep (the strict
+// upper triangle goes stale; the per-sweep recompute rewrites the whole matrix).
+// HBM-bound: 8 n^2 bytes per site (0.54 GB at n = 8192), nothing crosses to the host.
 // phi(z)/Phi(z) is evaluated as sqrt(2/pi) / erfcx(-z/sqrt 2): no cancellation for any z, equal to
 // the reference's exp(-z^2/2 - log sqrt(2 pi) - log_ndtr(z)) up to rounding.
 #include "gpx_internal.h"
@@ -28,7 +30,9 @@ __global__ __launch_bounds__(SITE_THREADS) void ep_site_kernel(int n, int i, con
   const double* row = Sigma + (long)i * ld;
   double acc = 0.0;
   for (int c = t; c < n; c += SITE_THREADS) {
-    const double v = row[c];
+    // column i of the symmetric Sigma from its LOWER triangle: the row part is contiguous, the part
+    // below the diagonal a strided gather (n - i elements; cheap next to the rank-1 update)
+    const double v = c <= i ? row[c] : Sigma[(long)c * ld + i];
     colbuf[c] = v;
     acc = fma(v, nu[c], acc);
   }
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(SITE_THREADS) void ep_site_kernel(int n, int i, con
   }
 }
 
-// Sigma[r][:] += coef * colbuf[r] * colbuf[:] for R1_ROWS rows per workgroup.
+// Sigma[r][c] += coef * colbuf[r] * colbuf[c] for c <= r (lower triangle), R1_ROWS rows per workgroup.
 __global__ __launch_bounds__(256) void ep_rank1_kernel(int n, double* Sigma, long ld, const double* colbuf,
                                                        const double* scal) {
   const int t = threadIdx.x;
@@ -68,8 +72,9 @@ __global__ __launch_bounds__(256) void ep_rank1_kernel(int n, double* Sigma, lon
 #pragma unroll
   for (int q = 0; q < R1_ROWS; ++q) f[q] = r0 + q < n ? coef * colbuf[r0 + q] : 0.0;
   const int nrows = min(R1_ROWS, n - r0);
-  for (int c = 2 * t; c < n; c += 512) {
-    if (c + 1 < n) {
+  const int cend = min(n, r0 + R1_ROWS);   // lower triangle only (plus the few upper entries of the diagonal 8x8 block)
+  for (int c = 2 * t; c < cend; c += 512) {
+    if (c + 1 < cend) {
       const v2d cv = *reinterpret_cast<const v2d*>(colbuf + c);
       v2d v[R1_ROWS];
 #pragma unroll

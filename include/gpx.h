@@ -180,8 +180,9 @@ int gpx_ep_recompute(gpx_handle* h, int n, const double* K, int ldk, const doubl
 /* One sweep of EP site updates on the device, sites visited strictly in the order given
  * (expectation_propagation.py:72-88: cavity, probit moment match, tau[i] / nu[i], the rank-1 update of
  * Sigma).  order_host: `count` site indices in HOST memory (the caller's np.random.permutation with the
- * frozen sites removed); y, tau, nu: device vectors of n; Sigma: n x ld device matrix, full symmetric,
- * updated in place; work: (n rounded up to even) + 2 device doubles.  mu is not maintained between
+ * frozen sites removed); y, tau, nu: device vectors of n; Sigma: n x ld device matrix, symmetric:
+ * only its LOWER triangle is read and updated in place (the strict upper triangle goes stale);
+ * work: (n rounded up to even) + 2 device doubles.  mu is not maintained between
  * sites (only mu[i] of the next site is ever read; it is formed from row i of Sigma and nu) -- call
  * gpx_ep_recompute after the sweep as the reference does (expectation_propagation.py:90-94).
  * Asynchronous on the handle's stream. */
