@@ -177,3 +177,25 @@ def test_generate_gp_same_X_as_reference_and_y_is_L_z():
     K2 = O.cov("rbf", X2, None, 2.0, 0.3)[0] + 0.05 * np.eye(700)
     assert relerr(y2, sla.cholesky(K2, lower=True) @ z2) < 1e-11
     assert generate_gp(5, random_state=0)[1].shape == (5,)
+
+
+def test_default_noise_stress_case_matches_oracle():
+    """SURVEY 8d stress case: the class-default noise variance 0.01 (regression.py:11) on the synthetic
+    ARD workload -- cond(Ky) is ~10x the headline's; LML, alpha, gradient, mean and variance still
+    within 1e-9 of the oracle (gradient relative to its own scale)."""
+    from gaussian_process_amd import ARD, GaussianProcessRegression
+    from oracle import gp_oracle as O
+    X, y, Xs, beta = O.synthetic_ard(2048, m=128, d=8, seed=2, noise=0.01)
+    gp = GaussianProcessRegression(ARD(sigma=1.0, beta=beta))          # sigma = 0.01 default
+    gp.fit(X, y)
+    lml_o, _, L = O.gpr_lml("ard", X, y, 1.0, beta, 0.01)
+    g_o, alpha_o = O.gpr_grad("ard", X, y, 1.0, beta, 0.01, spd_inverse=True)
+    mean_o, cov_o = O.gpr_predict("ard", X, y, Xs, 1.0, beta, 0.01, L=L)
+    assert abs(gp.log_marginal_likelihood() - lml_o) < 1e-9 * abs(lml_o)
+    assert relerr(gp.alpha_(), alpha_o) < 1e-9
+    g = gp.grad_log_marginal_likelihood()
+    scale = max(np.abs(v).max() for v in g_o.values())
+    for k in g_o:
+        assert np.abs(g[k] - g_o[k]).max() < 1e-9 * scale
+    mean, cov = gp.predict_with_variance(Xs)
+    assert relerr(mean, mean_o) < 1e-9 and relerr(cov, cov_o) < 1e-9
