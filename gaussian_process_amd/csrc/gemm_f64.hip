@@ -279,50 +279,105 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
       }
     };
 
+    // Software pipeline over k-tiles, one barrier per tile placed before the LAST MFMA k-step: by then
+    // this wave has read its last fragments of the current buffer (so the buffer may be overwritten)
+    // and the DMA of tile t+1, issued one tile earlier, has landed.  After the barrier the DMA of tile
+    // t+2 (into the buffer just released) and the first fragments of tile t+1 are issued BETWEEN the
+    // MFMAs of the last k-step, so neither costs MFMA issue time and no LDS round trip is exposed at
+    // the tile boundary.
+    constexpr int NMFMA = TM * TN, NPIECE = TA::PER_THREAD + TB::PER_THREAD, KL = BK / 4 - 1;
     stage_a(kb, 0);
     stage_b(kb, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (kb + BK < ke) {
+      gA += stepA;
+      gB += stepB;
+      stage_a(kb + BK, 1);
+      stage_b(kb + BK, 1);
+    }
+    double fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int x = 0; x < TM; ++x) fa[0][x] = pa[TA::frag_sel(wr * TM + x, 0)][TA::frag_off(wr * TM + x, 0)];
+#pragma unroll
+    for (int y = 0; y < TN; ++y) fb[0][y] = pb[TB::frag_sel(wc * TN + y, 0)][TB::frag_off(wc * TN + y, 0)];
     for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
 #pragma unroll
       for (int cur = 0; cur < 2; ++cur) {  // unrolled: the LDS buffer index is a compile-time constant
         const int kt = k0 + cur * BK;
         if (kt >= ke) break;
-        gA += stepA;
-        gB += stepB;
-        double fa[2][TM], fb[2][TN];
-        // first fragments of this tile: start the LDS reads, then issue the DMA under their latency
 #pragma unroll
-        for (int x = 0; x < TM; ++x)
-          fa[0][x] = pa[TA::frag_sel(wr * TM + x, 0)][cur * TA::ELEMS + TA::frag_off(wr * TM + x, 0)];
+        for (int kk = 0; kk < KL; ++kk) {
 #pragma unroll
-        for (int y = 0; y < TN; ++y)
-          fb[0][y] = pb[TB::frag_sel(wc * TN + y, 0)][cur * TB::ELEMS + TB::frag_off(wc * TN + y, 0)];
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + BK < ke) {  // next k-tile lands in the other buffer under this tile's MFMAs
-          stage_a(kt + BK, cur ^ 1);
-          stage_b(kt + BK, cur ^ 1);
-        }
+          for (int x = 0; x < TM; ++x)
+            fa[(kk + 1) & 1][x] =
+                pa[TA::frag_sel(wr * TM + x, kk + 1)][cur * TA::ELEMS + TA::frag_off(wr * TM + x, kk + 1)];
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-          if (kk + 1 < BK / 4) {
-#pragma unroll
-            for (int x = 0; x < TM; ++x)
-              fa[(kk + 1) & 1][x] =
-                  pa[TA::frag_sel(wr * TM + x, kk + 1)][cur * TA::ELEMS + TA::frag_off(wr * TM + x, kk + 1)];
-#pragma unroll
-            for (int y = 0; y < TN; ++y)
-              fb[(kk + 1) & 1][y] =
-                  pb[TB::frag_sel(wc * TN + y, kk + 1)][cur * TB::ELEMS + TB::frag_off(wc * TN + y, kk + 1)];
-          }
+          for (int y = 0; y < TN; ++y)
+            fb[(kk + 1) & 1][y] =
+                pb[TB::frag_sel(wc * TN + y, kk + 1)][cur * TB::ELEMS + TB::frag_off(wc * TN + y, kk + 1)];
 #pragma unroll
           for (int x = 0; x < TM; ++x)
 #pragma unroll
             for (int y = 0; y < TN; ++y)
               acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][x], fb[kk & 1][y], acc[x][y], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of the next tile has landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        const int kn = kt + 2 * BK;
+        const bool more = kn < ke;
+        const bool fast = more && !TA::needs_guard(i0, g.M, kn, ke, g.a_tri) &&
+                          !TB::needs_guard(j0, g.N, kn, ke, g.b_tri);
+        const char* sa = nullptr;
+        const char* sb = nullptr;
+        if (more) {
+          gA += stepA;
+          gB += stepB;
+          if (fast) {
+            sa = uniform_ptr(gA);
+            sb = uniform_ptr(gB);
+          } else {           // boundary tile: guarded loader, ahead of the MFMAs
+            stage_a(kn, cur);
+            stage_b(kn, cur);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < NMFMA; ++m) {
+          if (fast) {   // wave-uniform: piece q of the DMA goes in front of MFMA q * NMFMA / NPIECE
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) {
+              if (q * NMFMA / NPIECE == m) {
+                if (q < TA::PER_THREAD) {
+                  unsigned o = offA[q < TA::PER_THREAD ? q : 0];
+                  asm volatile("" : "+v"(o));
+                  glds16(sa + o, smA + cur * TA::ELEMS + (q * 4 + w) * 128);
+                } else {
+                  unsigned o = offB[q >= TA::PER_THREAD ? q - TA::PER_THREAD : 0];
+                  asm volatile("" : "+v"(o));
+                  glds16(sb + o, smB + cur * TB::ELEMS + ((q - TA::PER_THREAD) * 4 + w) * 128);
+                }
+              }
+            }
+          }
+          // fragment m of tile t+1's first k-step (of nothing useful after the last tile)
+          if (m < TM)
+            fa[0][m < TM ? m : 0] =
+                pa[TA::frag_sel(wr * TM + m, 0)][(cur ^ 1) * TA::ELEMS + TA::frag_off(wr * TM + m, 0)];
+          else if (m < TM + TN)
+            fb[0][m - TM < TN ? m - TM : 0] =
+                pb[TB::frag_sel(wc * TN + m - TM, 0)][(cur ^ 1) * TB::ELEMS + TB::frag_off(wc * TN + m - TM, 0)];
+          acc[m / TN][m % TN] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[KL & 1][m / TN], fb[KL & 1][m % TN],
+                                                                    acc[m / TN][m % TN], 0, 0, 0);
+        }
+#pragma unroll
+        for (int f = NMFMA; f < TM + TN; ++f) {  // small tiles: fragments that did not fit between the MFMAs
+          if (f < TM)
+            fa[0][f < TM ? f : 0] =
+                pa[TA::frag_sel(wr * TM + f, 0)][(cur ^ 1) * TA::ELEMS + TA::frag_off(wr * TM + f, 0)];
+          else
+            fb[0][f - TM < TN ? f - TM : 0] =
+                pb[TB::frag_sel(wc * TN + f - TM, 0)][(cur ^ 1) * TB::ELEMS + TB::frag_off(wc * TN + f - TM, 0)];
+        }
       }
     }
   }
