@@ -200,7 +200,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         """expectation_propagation.py:161-167: U = L^-1 diag(S) by TRSM, U^T U by the MFMA GEMM."""
         dv = self._dv
         rt = dv["rt"]
-        n = self.n
+        n = dv["n"]          # size of K: self.n here, 2 self.n under distillation.py
         U = self._solve_mat(dv, np.diag(self.S.ravel()))
         UtU = rt.matrix(n, n)
         _lib.check(rt.lib.gpx_gemm(rt.h, 1, 0, n, n, n, 1.0, ptr(U), U.shape[1], ptr(U), U.shape[1], 0.0,

@@ -18,6 +18,7 @@ Reference anchors (file:line in /root/reference/gaussian_process):
   gpr_lml            regression.py:46-55
   gpr_grad           regression.py:57-76
   ep_fit / ep_*      expectation_propagation.py:25-167
+  distillation_*     distillation.py:22-63
 
 Differences from the reference that do not change results beyond rounding:
   * the ARD Gram is accumulated one input dimension at a time and in row
@@ -210,15 +211,23 @@ def ep_site_update(i, yi, Sigma, mu, tau, nu):
     mu[:] = Sigma @ nu
 
 
-def ep_fit(K, y, max_sweeps=100, orders=None):
+def ep_fit(K, y, max_sweeps=100, orders=None, fix_index=None, nu_fixed=None, tau_fixed=None):
     """expectation_propagation.py:25-108 with shuffle=False (or explicit site orders).
 
+    ``fix_index`` / ``nu_fixed`` / ``tau_fixed``: sites whose natural parameters are given and never
+    updated (expectation_propagation.py:26-51, 73-74; used by distillation.py:33-35).
     Returns a dict with tau, nu, mu, Sigma, K (jittered), L, S, z, sweeps.
     """
     n = K.shape[0]
     K = K + EP_EPS * np.eye(n)
     tau = np.zeros(n)
     nu = np.zeros(n)
+    frozen = np.zeros(n, dtype=bool)
+    if fix_index is not None:
+        fix_index = np.asarray(fix_index, dtype=int)
+        frozen[fix_index] = True
+        tau[fix_index] = np.asarray(tau_fixed, dtype=float)
+        nu[fix_index] = np.asarray(nu_fixed, dtype=float)
     L, Sigma, mu, s = ep_recompute(K, tau, nu)
     sweeps = 0
     for c in range(max_sweeps):
@@ -226,6 +235,8 @@ def ep_fit(K, y, max_sweeps=100, orders=None):
         nu_old = nu.copy()
         order = np.arange(n) if orders is None else orders[c]
         for i in order:
+            if frozen[i]:
+                continue
             ep_site_update(int(i), y[i], Sigma, mu, tau, nu)
         L, Sigma, mu, s = ep_recompute(K, tau, nu)
         sweeps = c + 1
@@ -260,6 +271,49 @@ def ep_lml(state, y):
     t5 = 0.5 * nu_cav.dot((tau * mu_cav - 2.0 * nu) / (tau_cav + tau))
     t6 = np.sum(norm.logcdf(y * mu_cav / np.sqrt(1.0 + 1.0 / tau_cav)))
     return float(t0 + t1 + t2 + t3 + t4 + t5 + t6)
+
+
+# --------------------------------------------------------------------------
+# distillation: EP over a two-task Kronecker kernel -- distillation.py:22-63
+# --------------------------------------------------------------------------
+def distillation_kernel(K_, rho):
+    """distillation.py:27-32: kron([[1, rho], [rho, 1]], K_)."""
+    return np.kron(np.array([[1.0, rho], [rho, 1.0]]), K_)
+
+
+def distillation_fit(K_, y, s, rho, sigma, orders=None, max_sweeps=100):
+    """distillation.py:22-35: the n soft-label sites (indices n..2n-1) are fixed at
+    nu = s / sigma, tau = 1 / sigma; the n classification sites (0..n-1) are swept."""
+    n = K_.shape[0]
+    return ep_fit(distillation_kernel(K_, rho), y, max_sweeps=max_sweeps, orders=orders,
+                  fix_index=np.arange(n, 2 * n), nu_fixed=np.asarray(s, dtype=float) / sigma,
+                  tau_fixed=np.ones(n) / sigma)
+
+
+def distillation_posterior(state, Ks_, Kss, rho):
+    """distillation.py:40-44."""
+    return ep_posterior(state, np.vstack([Ks_, rho * Ks_]), Kss)
+
+
+def distillation_lml(state, y, tol=1e-7):
+    """distillation.py:46-63 as written, including its use of trace(L) in t0 and of the
+    soft-label half of the cavity parameters in t3 (SURVEY.md marks the formula as suspect;
+    the port keeps it so results stay comparable)."""
+    Sigma, mu, tau, nu, L, S = (state[k] for k in ("Sigma", "mu", "tau", "nu", "L", "S"))
+    n = len(y)
+    dS = np.diag(Sigma)
+    tau_cav = 1.0 / dS - tau
+    nu_cav = mu / dS - nu
+    t0 = -np.log(np.trace(L))
+    t1 = np.sum(np.log(S))
+    w = np.linalg.solve(L @ np.diag(S), nu)
+    t2 = -0.5 * w.dot(w)
+    t3 = np.sum(norm.logcdf(y * nu_cav[n:] / np.sqrt(tau_cav[n:] * (1.0 + tau_cav[n:]))))
+    assert np.all(tau_cav[n:] > tol)
+    assert np.all(tau[n:] > tol)
+    t4 = 0.5 * np.sum(np.log((1.0 / tau_cav + 1.0 / tau)[n:]))
+    t5 = 0.5 * np.sum(((nu_cav / tau_cav + nu / tau) ** 2 * (1.0 / tau_cav + 1.0 / tau))[n:])
+    return float(t0 + t1 + t2 + t3 + t4 + t5)
 
 
 # --------------------------------------------------------------------------

@@ -16,6 +16,11 @@ Cases:
   g2_ard2d         examples/ARD_regression_2d.ipynb cells 2-5 (n_train=100) incl. empirical Bayes
   g3_ard8_n{256,1024,4096}   synthetic ARD d=8 workload of SURVEY 8(d), m=256
   g4_ep_moons_n{50,200}      examples/expectation_propagation.ipynb split; _ep(K, shuffle=False)
+  g5_distill_rho{100,050,000}  examples/distillation_illustration.ipynb cells 2-5 (n_train=50),
+                             rho = 1, 0.5, 0: _ep(kron(Kt, K_), fixed soft-label sites, shuffle=False)
+                             and the public fit() under np.random.seed(0)
+
+``python tests/golden/make_golden.py g5`` regenerates only the cases whose name starts with g5.
 """
 import os
 import sys
@@ -28,13 +33,19 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, "/root/reference")
 sys.path.insert(0, ROOT)
 
-from gaussian_process import GaussianProcessRegression, GaussianProcessExpectationPropagation  # noqa: E402
+from gaussian_process import (GaussianProcessRegression, GaussianProcessExpectationPropagation,  # noqa: E402
+                              GaussianProcessDistillation)
 from gaussian_process.kernels import RBF, ARD  # noqa: E402
 from gaussian_process.datasets import generate_gp  # noqa: E402
 from oracle.gp_oracle import synthetic_ard  # noqa: E402  (input generator only)
 
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
+
+
 def save(name, **kw):
+    if not name.startswith(ONLY):
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in kw.items()})
     print("wrote", path, os.path.getsize(path), "bytes")
@@ -130,6 +141,43 @@ def main():
              diagL=np.diag(ep.L), z=ep.z, lml=lml, post_mean=pm, post_var=pv, decision=dec,
              score=np.mean(np.sign(dec - 0.5) == yte),
              grad_cov_sigma=grads["cov__sigma"], grad_cov_beta=grads["cov__beta"])
+
+    # ---- G5: distillation_illustration notebook ---------------------------
+    X, s = generate_gp(n_samples=100, random_state=6)
+    y = np.sign(s)
+    Xtr, Xte, ytr, yte, s_tr, s_te = train_test_split(X, y, s, train_size=0.5, random_state=0)
+    Xgrid = np.linspace(-3, 3).reshape(-1, 1)
+    for rho in (1.0, 0.5, 0.0):
+        gpd = GaussianProcessDistillation(cov=RBF(1, 1), sigma=0.01, rho=rho)
+        gpd.Xtr, gpd.ytr, gpd.str = Xtr, ytr, s_tr
+        gpd.n, gpd.dim = Xtr.shape
+        n = gpd.n
+        K_ = gpd.cov(Xtr).K
+        K = np.kron(np.array([[1, rho], [rho, 1]]), K_)
+        gpd._ep(K, fix_index=np.arange(n, 2 * n), nu_fixed=s_tr / gpd.sigma,
+                tau_fixed=np.ones(n) / gpd.sigma, shuffle=False)
+        pm, pv = gpd.posterior(Xgrid)
+        tm, tv = gpd.posterior(Xte)
+        dec = gpd.decision_function(Xte)
+        try:
+            lml = gpd.log_marginal_likelihood()
+        except AssertionError:
+            lml = np.nan          # distillation.py:55-56 asserts on the cavity precisions
+        try:
+            gpd.grad_log_marginal_likelihood()
+            grad_raises = ""
+        except Exception as e:    # distillation.py:65-81 -> expectation_propagation.py:163 shape mismatch
+            grad_raises = type(e).__name__
+        np.random.seed(0)
+        pub = GaussianProcessDistillation(cov=RBF(1, 1), sigma=0.01, rho=rho)
+        pub.fit(Xtr, ytr, s_tr)
+        qm, qv = pub.posterior(Xgrid)
+        save("g5_distill_rho%03d" % int(round(100 * rho)), Xtr=Xtr, ytr=ytr, s_tr=s_tr, Xte=Xte, yte=yte,
+             Xgrid=Xgrid, rho=rho, sigma=gpd.sigma, K_=K_, tau=gpd.tau_tilde, nu=gpd.nu_tilde, mu=gpd.mu,
+             diagSigma=np.diag(gpd.Sigma), diagL=np.diag(gpd.L), z=gpd.z, grid_mean=pm, grid_var=pv,
+             test_mean=tm, test_var=tv, decision=dec, score=np.mean(np.sign(dec - 0.5) == yte), lml=lml,
+             grad_raises=grad_raises, pub_tau=pub.tau_tilde, pub_nu=pub.nu_tilde, pub_grid_mean=qm,
+             pub_grid_var=qv, pub_score=pub.score(Xte, yte))
 
 
 if __name__ == "__main__":

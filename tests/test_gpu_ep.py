@@ -80,3 +80,55 @@ def test_ep_sweep_matches_oracle_site_by_site(n):
     bad = np.array([n], dtype=np.int32)
     assert rt.lib.gpx_ep_sweep(rt.h, n, ptr(dS), dS.shape[1], ptr(dy), ptr(dt), ptr(dn),
                                bad.ctypes.data_as(C.POINTER(C.c_int)), 1, ptr(work)) == -1
+
+
+@pytest.mark.parametrize("name", ["g5_distill_rho100", "g5_distill_rho050", "g5_distill_rho000"])
+def test_distillation_matches_reference(name):
+    """distillation.py through the device EP path (2n x 2n Kronecker prior, n fixed soft-label sites)
+    against fixtures made by the reference: deterministic order via _ep(shuffle=False), then the public
+    fit() under the same NumPy seed (examples/distillation_illustration.ipynb)."""
+    from gaussian_process_amd import GaussianProcessDistillation, RBF
+    g = load_golden(name)
+    rho, sigma = float(g["rho"]), float(g["sigma"])
+    gpd = GaussianProcessDistillation(cov=RBF(1, 1), sigma=sigma, rho=rho)
+    gpd.Xtr, gpd.ytr, gpd.str = g["Xtr"], g["ytr"], g["s_tr"]
+    gpd.n, gpd.dim = g["Xtr"].shape
+    n = gpd.n
+    K_ = gpd.cov(gpd.Xtr).K
+    assert relerr(K_, g["K_"]) < 1e-13
+    gpd._ep(np.kron(np.array([[1, rho], [rho, 1]]), g["K_"]), fix_index=np.arange(n, 2 * n),
+            nu_fixed=g["s_tr"] / sigma, tau_fixed=np.ones(n) / sigma, shuffle=False)
+    assert np.array_equal(gpd.tau_tilde[n:], np.ones(n) / sigma)      # fixed sites untouched
+    assert relerr(gpd.tau_tilde, g["tau"]) < 1e-7
+    assert relerr(gpd.nu_tilde, g["nu"]) < 1e-7
+    assert relerr(gpd.mu, g["mu"]) < 1e-7
+    assert relerr(np.diag(gpd.Sigma), g["diagSigma"]) < 1e-7
+    assert relerr(np.diag(gpd.L), g["diagL"]) < 1e-8
+    assert relerr(gpd.z, g["z"]) < 1e-7
+    pm, pv = gpd.posterior(g["Xgrid"])
+    assert relerr(pm, g["grid_mean"]) < 1e-7 and np.max(np.abs(pv - g["grid_var"])) < 1e-7
+    assert relerr(gpd.decision_function(g["Xte"]), g["decision"]) < 1e-7
+    assert abs(gpd.score(g["Xte"], g["yte"]) - float(g["score"])) < 1e-12
+    lml = gpd.log_marginal_likelihood()
+    assert abs(lml - float(g["lml"])) < 1e-7 * abs(float(g["lml"]))
+    assert len(gpd.log_marginal_likelihood(splitted_terms=True)) == 6
+    # the gradient (the reference raises here): both trace terms against NumPy from the fitted state
+    grads = gpd.grad_log_marginal_likelihood(splitted_terms=True)
+    assert set(grads) == {"rho", "sigma", "cov__sigma", "cov__beta"}
+    K = np.kron(np.array([[1, rho], [rho, 1]]), K_) + 1e-8 * np.eye(2 * n)
+    S = np.sqrt(gpd.tau_tilde)
+    U = np.linalg.solve(np.linalg.cholesky(np.eye(2 * n) + S[:, None] * K * S[None, :]), np.diag(S))
+    b = gpd.nu_tilde - U.T @ U @ K @ gpd.nu_tilde
+    dK = np.kron(np.array([[0.0, 1.0], [1.0, 0.0]]), K_)
+    assert abs(grads["rho"][0] - 0.5 * b @ dK @ b) < 1e-7 * max(1.0, abs(0.5 * b @ dK @ b))
+    assert abs(grads["rho"][1] - 0.5 * np.trace(U.T @ U @ dK)) < 1e-7 * max(1.0, abs(0.5 * np.trace(U.T @ U @ dK)))
+    # public API, RNG-driven site order
+    np.random.seed(0)
+    pub = GaussianProcessDistillation(cov=RBF(1, 1), sigma=sigma, rho=rho)
+    pub.fit(g["Xtr"], g["ytr"], g["s_tr"])
+    qm, qv = pub.posterior(g["Xgrid"])
+    assert relerr(pub.tau_tilde, g["pub_tau"]) < 1e-6 and relerr(qm, g["pub_grid_mean"]) < 1e-6
+    assert abs(pub.score(g["Xte"], g["yte"]) - float(g["pub_score"])) < 1e-12
+    pub.set_params(rho=0.25)
+    pub.refit()
+    assert pub.tau_tilde.shape == (2 * n,)

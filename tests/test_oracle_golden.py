@@ -94,3 +94,23 @@ def test_ep_matches_reference(name):
     pm, pv = O.ep_posterior(st, Ks, np.ones(g["Xte"].shape[0]))
     assert relerr(pm, g["post_mean"]) < 1e-8
     assert relerr(pv, g["post_var"]) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["g5_distill_rho100", "g5_distill_rho050", "g5_distill_rho000"])
+def test_distillation_matches_reference(name):
+    """distillation.py:22-63 (EP with the soft-label sites fixed) against the reference's own outputs."""
+    g = load_golden(name)
+    rho, sigma = float(g["rho"]), float(g["sigma"])
+    st = O.distillation_fit(g["K_"], g["ytr"], g["s_tr"], rho, sigma)
+    n = len(g["ytr"])
+    assert np.array_equal(st["tau"][n:], np.ones(n) / sigma)
+    for key, ref in (("tau", "tau"), ("nu", "nu"), ("mu", "mu"), ("z", "z")):
+        assert relerr(st[key], g[ref]) < 1e-7, key
+    assert relerr(np.diag(st["Sigma"]), g["diagSigma"]) < 1e-7
+    assert relerr(np.diag(st["L"]), g["diagL"]) < 1e-8
+    Ks_, _, _ = O.rbf_cov(g["Xtr"], g["Xgrid"], 1.0, 1.0, want_grad=False)
+    pm, pv = O.distillation_posterior(st, Ks_, np.ones(g["Xgrid"].shape[0]), rho)
+    assert relerr(pm, g["grid_mean"]) < 1e-7
+    assert np.max(np.abs(pv - g["grid_var"])) < 1e-7
+    assert abs(O.distillation_lml(st, g["ytr"]) - float(g["lml"])) < 1e-7 * abs(float(g["lml"]))
+    assert str(g["grad_raises"]) == "ValueError"       # the reference's gradient cannot be evaluated
