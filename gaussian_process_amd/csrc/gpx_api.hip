@@ -652,8 +652,9 @@ int gpx_ep_sweep(gpx_handle* h, int n, double* Sigma, int ld, const double* y, d
   GPX_REQUIRE(gpx_aligned16(work), "ep_sweep: work must be 16-byte aligned");
   if (count == 0) return 0;
   DeviceGuard dg(h->device);
-  const size_t n_even = ((size_t)n + 1) & ~(size_t)1;
-  return gpx_ep_sweep_launch(h->stream, n, Sigma, ld, y, tau, nu, order_host, count, work, work + n_even);
+  return gpx_ep_sweep_launch(h->stream, n, Sigma, ld, y, tau, nu, order_host, count, work);
 }
+
+size_t gpx_ep_sweep_work_elems(int n) { return n > 0 ? gpx_ep_sweep_work_elems_impl(n) : 0; }
 
 }  // extern "C"

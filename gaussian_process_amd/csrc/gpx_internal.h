@@ -85,9 +85,12 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int n
 int gpx_trsv_launch(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv, double* x,
                     long incx, double* red, size_t red_elems);
 
-// ep.hip: one sweep of site updates in the given order; colbuf n doubles, scal 2 doubles (device)
+// ep.hip: one sweep of site updates in the given order, rank-1 updates delayed GPX_EP_BLOCK at a time;
+// work: gpx_ep_sweep_work_elems_impl(n) device doubles
+constexpr int GPX_EP_BLOCK = 256;
+size_t gpx_ep_sweep_work_elems_impl(int n);
 int gpx_ep_sweep_launch(hipStream_t s, int n, double* Sigma, long ld, const double* y, double* tau, double* nu,
-                        const int* order_host, int count, double* colbuf, double* scal);
+                        const int* order_host, int count, double* work);
 
 // blas2.hip
 int gpx_logdet_launch(hipStream_t s, int n, const double* L, long ldl, double* red, double* out_dev);

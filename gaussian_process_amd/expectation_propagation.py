@@ -113,7 +113,8 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         rt.bind_stream()
         dv = dict(rt=rt, n=n, K=rt.upload_matrix(K), B=rt.matrix(n, n), V=rt.matrix(n, n),
                   Sigma=rt.matrix(n, n), dinv=rt.dinv(n), tau=rt.upload_vector(tau), nu=rt.upload_vector(nu),
-                  s=rt.vector(n), mu=rt.vector(n), y=rt.upload_vector(y), work=rt.vector(n + 4))
+                  s=rt.vector(n), mu=rt.vector(n), y=rt.upload_vector(y),
+                  work=rt.vector(int(rt.lib.gpx_ep_sweep_work_elems(n))))
         self._recompute(dv)
 
         order = np.arange(n)

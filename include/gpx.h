@@ -179,15 +179,18 @@ int gpx_ep_recompute(gpx_handle* h, int n, const double* K, int ldk, const doubl
 
 /* One sweep of EP site updates on the device, sites visited strictly in the order given
  * (expectation_propagation.py:72-88: cavity, probit moment match, tau[i] / nu[i], the rank-1 update of
- * Sigma).  order_host: `count` site indices in HOST memory (the caller's np.random.permutation with the
- * frozen sites removed); y, tau, nu: device vectors of n; Sigma: n x ld device matrix, symmetric:
- * only its LOWER triangle is read and updated in place (the strict upper triangle goes stale);
- * work: (n rounded up to even) + 2 device doubles.  mu is not maintained between
- * sites (only mu[i] of the next site is ever read; it is formed from row i of Sigma and nu) -- call
- * gpx_ep_recompute after the sweep as the reference does (expectation_propagation.py:90-94).
+ * Sigma, mu = Sigma nu).  order_host: `count` site indices in HOST memory (the caller's
+ * np.random.permutation with the frozen sites removed); y, tau, nu: device vectors of n; Sigma: n x ld
+ * device matrix, symmetric: only its LOWER triangle is read and updated in place (the strict upper
+ * triangle goes stale).  The rank-1 updates are delayed and applied 256 at a time by the MFMA GEMM; the
+ * result equals the site-by-site recursion up to rounding.  mu is carried inside the sweep but not
+ * returned -- call gpx_ep_recompute after the sweep as the reference does
+ * (expectation_propagation.py:90-94).  work: gpx_ep_sweep_work_elems(n) device doubles, 16-byte aligned.
  * Asynchronous on the handle's stream. */
 int gpx_ep_sweep(gpx_handle* h, int n, double* Sigma, int ld, const double* y, double* tau, double* nu,
                  const int* order_host, int count, double* work);
+/* Number of doubles gpx_ep_sweep needs in `work` for n sites (2 n x 256 delayed columns + 6 n state). */
+size_t gpx_ep_sweep_work_elems(int n);
 
 #ifdef __cplusplus
 }

@@ -69,7 +69,7 @@ def test_ep_sweep_matches_oracle_site_by_site(n):
     rt = runtime()
     rt.bind_stream()
     dS, dy, dt, dn, work = rt.upload_matrix(Sigma), rt.upload_vector(y), rt.upload_vector(tau0), \
-        rt.upload_vector(nu0), rt.vector(n + 4)
+        rt.upload_vector(nu0), rt.vector(int(rt.lib.gpx_ep_sweep_work_elems(n)))
     o32 = np.ascontiguousarray(order, dtype=np.int32)
     _lib.check(rt.lib.gpx_ep_sweep(rt.h, n, ptr(dS), dS.shape[1], ptr(dy), ptr(dt), ptr(dn),
                                    o32.ctypes.data_as(C.POINTER(C.c_int)), len(o32), ptr(work)), "gpx_ep_sweep")

@@ -30,7 +30,7 @@ gp._sweep, gp._recompute = timed("sweep", orig_sweep), timed("recompute", orig_r
 t0 = time.perf_counter()
 gp._ep(K)
 tot = time.perf_counter() - t0
-print("EP n=%d: %d sweeps, total %.2f s; site sweep %.3f s each (%.1f us/site, %.0f GB/s of Sigma traffic); recompute %.3f s each"
+print("EP n=%d: %d sweeps, total %.2f s; site sweep %.3f s each (%.1f us/site; the reference's rank-1 form would move %.0f GB per sweep); recompute %.3f s each"
       % (n, len(tim["sweep"]), tot, np.mean(tim["sweep"]), 1e6 * np.mean(tim["sweep"]) / n,
-         8.0 * n * n * n / np.mean(tim["sweep"]) / 1e9, np.mean(tim["recompute"][1:])), flush=True)
+         16.0 * n * n * n / 1e9, np.mean(tim["recompute"][1:])), flush=True)
 print("train accuracy %.4f  LML %.6f" % (np.mean(gp.predict(X[:2000]) == y[:2000]), gp.log_marginal_likelihood()), flush=True)
