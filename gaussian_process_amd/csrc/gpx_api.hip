@@ -4,6 +4,8 @@
 #include <cmath>
 #include <vector>
 
+#include <cstdlib>
+
 #include "gpx_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -104,9 +106,40 @@ int trsm_ltn(hipStream_t s, int n, int m, const double* L, long ldl, const doubl
   return trsm_ltn(s, n1, m, L, ldl, dinv, B, ldb);
 }
 
+// Right-looking Cholesky by 128-column panels for the small diagonal blocks the recursion ends in:
+// leaf (factor + inverse of the 128 x 128 diagonal block), one in-place GEMM for the panel below it,
+// one lower rank-128 update of the rest -- 3 dependent launches per panel where the recursion needs
+// ~8 (its solves and updates split further); the block is latency-bound, not flop-bound.
+int potrf_panels(hipStream_t s, int n, double* A, long lda, double* dinv, int* info_dev, int off) {
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int jb = n - j0 < NB ? n - j0 : NB;
+    double* Ajj = A + (long)j0 * lda + j0;
+    double* dj = dinv + (size_t)(j0 / NB) * NB * NB;
+    GPX_TRY(gpx_leaf_potf2_inv(s, jb, Ajj, lda, dj, info_dev, off + j0));
+    const int rem = n - j0 - jb;
+    if (rem <= 0) break;
+    double* A21 = Ajj + (long)jb * lda;
+    double* A22 = A21 + jb;
+    GPX_TRY(trsm_rlt(s, rem, jb, Ajj, lda, dj, A21, lda));
+    GemmDesc g = mk(A21, lda, GPX_LAY_KC, A21, lda, GPX_LAY_KC, A22, lda, A22, lda, rem, rem, jb, -1.0, 1.0);
+    g.c_lower = 1;
+    GPX_TRY(gpx_gemm_launch(s, g));
+  }
+  return 0;
+}
+
+int potrf_panel_limit() {
+  static const int lim = [] {
+    const char* e = getenv("GPX_POTRF_PANELS");   // development override
+    return e ? atoi(e) : 4096;
+  }();
+  return lim;
+}
+
 // recursive lower Cholesky; `off` = global index of A[0][0] (for info and the dinv block index)
 int potrf_rec(hipStream_t s, int n, double* A, long lda, double* dinv, int* info_dev, int off) {
   if (n <= NB) return gpx_leaf_potf2_inv(s, n, A, lda, dinv, info_dev, off);
+  if (n <= potrf_panel_limit()) return potrf_panels(s, n, A, lda, dinv, info_dev, off);
   const int n1 = split_point(n), n2 = n - n1;
   GPX_TRY(potrf_rec(s, n1, A, lda, dinv, info_dev, off));
   double* A21 = A + (long)n1 * lda;
