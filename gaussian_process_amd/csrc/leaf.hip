@@ -25,6 +25,7 @@
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int NB = GPX_NB;       // 128
 constexpr int LD = NB + 2;       // 130: (l & 15) * LD + (l >> 4) hits 32 distinct 8-byte banks per half wave
@@ -32,17 +33,28 @@ constexpr int TS = 16;           // tile size = MFMA M = N
 constexpr int NT = NB / TS;      // 8 tiles per side
 constexpr int THREADS = 512;     // 8 waves
 
+#ifdef GPX_LEAF_PROFILE   // tools/leaf_profile.hip: cycle stamps of the phases, thread 0
+__device__ long long leaf_prof[64];
+#define LEAF_TICK(k) do { if (threadIdx.x == 0) leaf_prof[k] = clock64(); } while (0)
+#else
+#define LEAF_TICK(k)
+#endif
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(p) to full double precision: hardware estimate + two Newton-Raphson steps.
+// 1/sqrt(p) to full double precision: hardware estimate (relative error ~2^-23) + one third-order
+// correction step (error -> 5/16 e^3; measured 2.2e-16 against a host Cholesky, same as with two steps).
 __device__ __forceinline__ double rsqrt_nr(double p) {
   double r = __builtin_amdgcn_rsq(p);
+#ifndef GPX_LEAF_NR
+#define GPX_LEAF_NR 1
+#endif
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < GPX_LEAF_NR; ++it) {
     const double e = fma(-p * r, r, 1.0);          // 1 - p r^2
     r = fma(r, fma(e, 0.375 * e, 0.5 * e), r);     // r (1 + e/2 + 3 e^2 / 8)
   }
@@ -86,7 +98,10 @@ __device__ __forceinline__ void inv_level(double* S, int base, int jc, bool acti
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       v4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k = jc; k < M; ++k) acc = tile_mm(S, base + M + i, base + k, base + k, base + jc, acc, 1.0, lane);
+      // k < jc multiplies a zero tile (Ainv is lower triangular and the tiles above the diagonal hold
+      // zeros): the static trip count lets the LDS reads of all k be in flight together
+#pragma unroll
+      for (int k = 0; k < M; ++k) acc = tile_mm(S, base + M + i, base + k, base + k, base + jc, acc, 1.0, lane);
       t[i] = acc;
     }
   }
@@ -102,162 +117,259 @@ __device__ __forceinline__ void inv_level(double* S, int base, int jc, bool acti
   }
 }
 
-// In place: lower triangle of S (L, diagonal reciprocals in rp) -> L^-1.  Entered after a barrier
-// that makes S and rp visible; leaves a barrier-synchronised result.  Strict upper parts of the
-// diagonal tiles must be (and stay) zero; tiles above the diagonal are never touched.
-__device__ void invert_lower(double* S, const double* rp) {
+// Inverse of one 16x16 lower-triangular tile by substitution, lane (l & 15) = column j of the inverse;
+// Lt: the tile in LDS (row stride ldt), rp: reciprocals of its diagonal, W: 16 x WS output.
+constexpr int WS = TS + 2;   // row stride of the tile inverses kept in LDS (conflict-free B-fragment reads)
+__device__ __forceinline__ void tile_inverse(const double* Lt, int ldt, const double* rp, double* W, int lane) {
+  const int j = lane & 15;
+  double w[TS];
+#pragma unroll
+  for (int i = 0; i < TS; ++i) {
+    double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) acc = fma(-Lt[i * ldt + k], w[k], acc);   // uniform address: LDS broadcast
+    w[i] = acc * rp[i];
+  }
+  if (lane < TS) {
+#pragma unroll
+    for (int i = 0; i < TS; ++i) W[i * WS + j] = w[i];                    // w[i] = 0 for i < j
+  }
+}
+
+// In place: lower triangle of S (L) -> L^-1, given the inverses of the 8 diagonal tiles in Wall
+// (8 x 16 x WS).  Entered after a barrier that makes S and Wall visible; leaves a barrier-synchronised
+// result.  Tiles above the diagonal must be (and stay) zero.
+__device__ void invert_lower(double* S, const double* Wall) {
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  // level 0: diagonal tile `wid`, lane (l & 15) = column j of the tile's inverse
-  {
-    const int o = wid * TS, j = lane & 15;
-    const double* Lt = S + o * LD + o;
-    double w[TS];
-#pragma unroll
-    for (int i = 0; i < TS; ++i) {
-      double acc = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < i; ++k) acc = fma(-Lt[i * LD + k], w[k], acc);   // uniform address: LDS broadcast
-      w[i] = acc * rp[o + i];
-    }
-    if (lane < TS) {
-#pragma unroll
-      for (int i = 0; i < TS; ++i) S[(o + i) * LD + o + j] = w[i];          // w[i] = 0 for i < j
-    }
+  // level 0: the diagonal tiles are already inverted; put them in place
+  for (int e = t; e < NT * TS * TS; e += THREADS) {
+    const int d = e >> 8, i = (e >> 4) & 15, j = e & 15;
+    S[(d * TS + i) * LD + d * TS + j] = Wall[(d * TS + i) * WS + j];
   }
   __syncthreads();
+  LEAF_TICK(30);
   inv_level<1>(S, 2 * (wid & 3), 0, wid < 4, lane);                         // four 32-blocks
   __syncthreads();
+  LEAF_TICK(31);
   inv_level<2>(S, 4 * ((wid >> 1) & 1), wid & 1, wid < 4, lane);            // two 64-blocks
   __syncthreads();
+  LEAF_TICK(32);
   inv_level<4>(S, 0, wid & 3, wid < 4, lane);                               // the 128-block
   __syncthreads();
+  LEAF_TICK(33);
+}
+
+// Phase A of panel p, one wave: factor the 16x16 diagonal tile in registers and invert it.
+// Lanes 0-15 hold row r of the tile (v[c] = A[r][c]), lanes 16-31 column r of W = L_tile^-1
+// (v[c] = W[c][r], starting from the identity).  The column sweep of the factorisation,
+// a[c] -= a[j] L[c][j], and of the inversion, w[c] -= w[j] L[c][j], are the SAME instruction on the two
+// lane groups: the tile inverse costs no extra issue slots.  Pivots and multipliers travel by
+// v_readlane from lanes 0-15 (no LDS round trip, no barrier); 1/sqrt by v_rsq_f64 + one correction.
+__device__ __forceinline__ void diag_tile(double* S, double* Wall, int p, int* fail, int lane) {
+  const int p0 = p * TS;
+  double* Wt = Wall + p * TS * WS;
+  const int r = lane & 15;
+  const bool inv = (lane & 16) != 0;
+  double v[TS];
+#pragma unroll
+  for (int c = 0; c < TS; ++c) {
+    const double a = S[(p0 + r) * LD + p0 + c];
+    v[c] = inv ? (c == r ? 1.0 : 0.0) : a;
+  }
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < TS; ++j) {
+    const double d = readlane_f64(v[j], j);
+    if (!(d > 0.0) && bad == 0) bad = p0 + j + 1;
+    v[j] *= rsqrt_nr(d);                         // L[r][j] (row j: d / sqrt(d) = L_jj)  |  W[j][r] final
+#pragma unroll
+    for (int c = j + 1; c < TS; ++c) {
+      const double lcj = readlane_f64(v[j], c);  // L[c][j]
+      v[c] = fma(-v[j], lcj, v[c]);
+    }
+  }
+  if (lane < TS) {
+#pragma unroll
+    for (int c = 0; c < TS; ++c) S[(p0 + r) * LD + p0 + c] = c <= r ? v[c] : 0.0;
+  } else if (lane < 2 * TS) {
+#pragma unroll
+    for (int c = 0; c < TS; ++c) Wt[c * WS + r] = v[c];   // W[c][r], zero for c < r
+  }
+  if (lane == 0 && bad != 0 && *fail == 0) *fail = bad;
 }
 
 // Factor the (padded) 128x128 SPD block in S in place (lower triangle; strict upper parts of the
-// diagonal tiles are zeroed).  rp[j] = 1 / L[j][j].  *fail = first non-positive pivot + 1 (0 = ok).
-__device__ void factor_lower(double* S, double* rp, double* Ltile, int* fail) {
+// diagonal tiles are zeroed) and leave the inverses of the 8 diagonal 16x16 tiles in Wall.
+// *fail = first non-positive pivot + 1 (0 = ok).  Per panel p of 16 columns:
+//   B  the 16-row tiles below the diagonal tile, one per wave: X <- X W^T on the matrix cores
+//      (A fragment X[l & 15][4s + (l >> 4)], B fragment W^T[4s + (l >> 4)][l & 15] = W[l & 15][4s + (l >> 4)])
+//   C  trailing lower tiles (ti >= tj > p) -= P_ti P_tj^T.  Wave 0 takes the next diagonal tile and
+//      goes straight on to phase A of panel p + 1 (the longest serial piece) while waves 1-7 share the
+//      other tiles, <= 4 each, processed together: all LDS reads first, the MFMA chains interleaved,
+//      then the writes.
+// Two barriers per panel.
+__device__ void factor_lower(double* S, double* Wall, int* fail) {
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  for (int p = 0; p < NT; ++p) {
+  if (wid == 0) diag_tile(S, Wall, 0, fail, lane);
+  __syncthreads();
+  LEAF_TICK(2);
+  for (int p = 0; p + 1 < NT; ++p) {
     const int p0 = p * TS;
-    // ---- A: diagonal tile, wave 0, lane (l & 15) = row
+    const double* Wt = Wall + p * TS * WS;
+    {
+      const int ti = p + 1 + wid;
+      if (ti < NT) {
+        const double* px = S + (ti * TS + (lane & 15)) * LD + p0 + (lane >> 4);
+        const double* pw = Wt + (lane & 15) * WS + (lane >> 4);
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(px[4 * s4], pw[4 * s4], acc, 0, 0, 0);
+        tile_store(S, ti, p, acc, lane);
+      }
+    }
+    __syncthreads();
+    LEAF_TICK(3 + 2 * p);
     if (wid == 0) {
-      const int r = lane & 15;
-      double a[TS], rpj[TS];
+      const int tn = p + 1;
+      double* pc = S + (tn * TS + (lane >> 4)) * LD + tn * TS + (lane & 15);
+      const double* pa = S + (tn * TS + (lane & 15)) * LD + p0 + (lane >> 4);
+      v4d acc;
 #pragma unroll
-      for (int c = 0; c < TS; ++c) a[c] = S[(p0 + r) * LD + p0 + c];
-      int bad = 0;
+      for (int r = 0; r < 4; ++r) acc[r] = pc[4 * r * LD];
 #pragma unroll
-      for (int j = 0; j < TS; ++j) {
-        const double d = readlane_f64(a[j], j);
-        if (!(d > 0.0) && bad == 0) bad = p0 + j + 1;
-        const double rs = rsqrt_nr(d);
-        rpj[j] = rs;
-        a[j] *= rs;                                  // row j: d / sqrt(d) = L_jj; rows below: L_ij
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * r], pa[4 * r], acc, 0, 0, 0);
 #pragma unroll
-        for (int c = j + 1; c < TS; ++c) {
-          const double lcj = readlane_f64(a[j], c);  // L[c][j]
-          a[c] = fma(-a[j], lcj, a[c]);
+      for (int r = 0; r < 4; ++r) pc[4 * r * LD] = acc[r];
+      diag_tile(S, Wall, tn, fail, lane);      // same wave: its LDS writes above are ordered before these reads
+    } else {
+      const int m = NT - p - 1, ntile = m * (m + 1) / 2;   // tile 0 of the triangle is wave 0's
+      double* pc[4];
+      const double* pa[4];
+      const double* pb[4];
+      v4d acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = wid + 7 * q;
+        if (c < ntile) {
+          int row = 0;
+          while ((row + 1) * (row + 2) / 2 <= c) ++row;   // wave-uniform, <= 7 steps
+          const int ti = p + 1 + row, tj = p + 1 + c - row * (row + 1) / 2;
+          pc[q] = S + (ti * TS + (lane >> 4)) * LD + tj * TS + (lane & 15);
+          pa[q] = S + (ti * TS + (lane & 15)) * LD + p0 + (lane >> 4);
+          pb[q] = S + (tj * TS + (lane & 15)) * LD + p0 + (lane >> 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[q][r] = pc[q][4 * r * LD];
         }
       }
-      if (lane < TS) {
 #pragma unroll
-        for (int c = 0; c < TS; ++c) {
-          const double v = c <= r ? a[c] : 0.0;
-          S[(p0 + r) * LD + p0 + c] = v;
-          Ltile[r * TS + c] = v;
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (wid + 7 * q < ntile)
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[q][4 * r], pb[q][4 * r], acc[q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (wid + 7 * q < ntile) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pc[q][4 * r * LD] = acc[q][r];
         }
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < TS; ++j) rp[p0 + j] = rpj[j];
-        if (bad != 0 && *fail == 0) *fail = bad;
-      }
     }
     __syncthreads();
-    // ---- B: rows below the tile, one lane per row: x <- x Ltile^-T
-    const int below = NB - p0 - TS;
-    if (t < below) {
-      double* row = S + (p0 + TS + t) * LD + p0;
-      double x[TS];
+    LEAF_TICK(4 + 2 * p);
+  }
+}
+
+// S <- lower triangle of the nb x nb block at A, identity-padded to 128 x 128, zeros above the
+// diagonal.  16-byte loads, all 16 of a thread in flight before the first LDS write (the loop it
+// replaces took 15 us of dependent scalar loads).  Reads A[i][i+1] next to a diagonal element: inside
+// the row because lda is even and >= n.
+__device__ __forceinline__ void load_block(double* S, const double* A, long lda, int nb) {
+  constexpr int PER = NB * NB / 2 / THREADS;   // 16 pairs per thread
+  v2d v[PER];
 #pragma unroll
-      for (int c = 0; c < TS; ++c) x[c] = row[c];
+  for (int u = 0; u < PER; ++u) {
+    const int q = threadIdx.x + THREADS * u;
+    const int i = q >> 6, j = (q & 63) * 2;
+    v[u] = (i < nb && j <= i) ? *reinterpret_cast<const v2d*>(A + (long)i * lda + j) : v2d{0.0, 0.0};
+  }
 #pragma unroll
-      for (int k = 0; k < TS; ++k) {
-        x[k] *= rp[p0 + k];
+  for (int u = 0; u < PER; ++u) {
+    const int q = threadIdx.x + THREADS * u;
+    const int i = q >> 6, j = (q & 63) * 2;
+    v2d w;
+    w.x = (i < nb && j <= i) ? v[u].x : (i == j ? 1.0 : 0.0);
+    w.y = (i < nb && j + 1 <= i) ? v[u].y : (i == j + 1 ? 1.0 : 0.0);
+    *reinterpret_cast<v2d*>(S + i * LD + j) = w;
+  }
+}
+
+// nb x nb block at A <- lower triangle of S, zeros above the diagonal.
+__device__ __forceinline__ void store_block(const double* S, double* A, long lda, int nb) {
+  constexpr int PER = NB * NB / 2 / THREADS;
 #pragma unroll
-        for (int c = k + 1; c < TS; ++c) x[c] = fma(-x[k], Ltile[c * TS + k], x[c]);
-      }
-#pragma unroll
-      for (int c = 0; c < TS; ++c) row[c] = x[c];
-    }
-    __syncthreads();
-    // ---- C: trailing lower tiles (ti >= tj > p) -= P_ti P_tj^T, dealt round-robin to the waves
-    int cnt = 0;
-    for (int ti = p + 1; ti < NT; ++ti) {
-      for (int tj = p + 1; tj <= ti; ++tj, ++cnt) {
-        if ((cnt & 7) != wid) continue;
-        double* pc = S + (ti * TS + (lane >> 4)) * LD + tj * TS + (lane & 15);
-        v4d acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = pc[4 * r * LD];
-        const double* pa = S + (ti * TS + (lane & 15)) * LD + p0 + (lane >> 4);
-        const double* pb = S + (tj * TS + (lane & 15)) * LD + p0 + (lane >> 4);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * s], pb[4 * s], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pc[4 * r * LD] = acc[r];
-      }
-    }
-    __syncthreads();
+  for (int u = 0; u < PER; ++u) {
+    const int q = threadIdx.x + THREADS * u;
+    const int i = q >> 6, j = (q & 63) * 2;
+    if (i >= nb || j >= nb) continue;
+    v2d w = *reinterpret_cast<const v2d*>(S + i * LD + j);
+    if (j > i) w.x = 0.0;
+    if (j + 1 > i) w.y = 0.0;
+    if (j + 1 < nb) *reinterpret_cast<v2d*>(A + (long)i * lda + j) = w;
+    else A[(long)i * lda + j] = w.x;
   }
 }
 
 __device__ __forceinline__ void store_dinv(const double* S, double* dinv) {
-  for (int e = threadIdx.x; e < NB * NB; e += THREADS) {
-    const int i = e >> 7, j = e & 127;
-    dinv[e] = j <= i ? S[i * LD + j] : 0.0;
+  constexpr int PER = NB * NB / 2 / THREADS;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int q = threadIdx.x + THREADS * u;
+    const int i = q >> 6, j = (q & 63) * 2;
+    v2d w = *reinterpret_cast<const v2d*>(S + i * LD + j);
+    if (j > i) w.x = 0.0;
+    if (j + 1 > i) w.y = 0.0;
+    *reinterpret_cast<v2d*>(dinv + i * NB + j) = w;
   }
 }
 
 __global__ __launch_bounds__(THREADS) void leaf_blocked_kernel(int nb, double* A, long lda, double* dinv,
                                                                int* info, int global_off) {
   __shared__ double S[NB * LD];
-  __shared__ double Ltile[TS * TS];
-  __shared__ double rp[NB];
+  __shared__ double Wall[NT * TS * WS];
   __shared__ int fail;
   const int t = threadIdx.x;
+  LEAF_TICK(0);
   if (t == 0) fail = 0;
-  for (int e = t; e < NB * NB; e += THREADS) {
-    const int i = e >> 7, j = e & 127;
-    S[i * LD + j] = (i < nb && j <= i) ? A[(long)i * lda + j] : (i == j ? 1.0 : 0.0);
-  }
+  load_block(S, A, lda, nb);
   __syncthreads();
-  factor_lower(S, rp, Ltile, &fail);
-  for (int e = t; e < nb * nb; e += THREADS) {
-    const int i = e / nb, j = e - i * nb;
-    A[(long)i * lda + j] = j <= i ? S[i * LD + j] : 0.0;
-  }
+  LEAF_TICK(1);
+  factor_lower(S, Wall, &fail);
+  store_block(S, A, lda, nb);
   if (t == 0 && fail != 0 && fail <= nb && *info == 0) *info = global_off + fail;
   __syncthreads();
-  invert_lower(S, rp);
+  LEAF_TICK(29);
+  invert_lower(S, Wall);
   store_dinv(S, dinv);
+  LEAF_TICK(34);
 }
 
 // dinv for an existing factor: one workgroup per diagonal block.
 __global__ __launch_bounds__(THREADS) void leaf_blocked_inv_kernel(int n, const double* L, long ldl, double* dinv) {
   __shared__ double S[NB * LD];
+  __shared__ double Wall[NT * TS * WS];
   __shared__ double rp[NB];
   const int t = threadIdx.x;
   const int off = blockIdx.x * NB;
   const int nb = min(NB, n - off);
   const double* A = L + (long)off * ldl + off;
-  for (int e = t; e < NB * NB; e += THREADS) {
-    const int i = e >> 7, j = e & 127;
-    S[i * LD + j] = (i < nb && j <= i) ? A[(long)i * ldl + j] : (i == j ? 1.0 : 0.0);
-  }
+  load_block(S, A, ldl, nb);
   if (t < NB) rp[t] = t < nb ? 1.0 / A[(long)t * ldl + t] : 1.0;
   __syncthreads();
-  invert_lower(S, rp);
+  const int wid = t >> 6;
+  tile_inverse(S + wid * TS * LD + wid * TS, LD, rp + wid * TS, Wall + wid * TS * WS, t & 63);
+  __syncthreads();
+  invert_lower(S, Wall);
   store_dinv(S, dinv + (size_t)blockIdx.x * NB * NB);
 }
 
