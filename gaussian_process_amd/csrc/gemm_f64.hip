@@ -145,9 +145,9 @@ struct Tile {
 // (idx / 64) * 8 + xcd, so the 64 workgroups resident on one XCD work on one 8 x 8 super-tile
 // (8 A panels + 8 B panels in its private L2) and super-tiles are dealt round-robin over the XCDs
 // (balanced also when the work per tile varies, as with triangular operands).
-__device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower, unsigned nsuper, int& bi,
-                                             int& bj) {
-  const unsigned bid = blockIdx.x;
+__device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower, unsigned nsuper, unsigned bid0,
+                                             int& bi, int& bj) {
+  const unsigned bid = blockIdx.x + bid0;
   if (nsuper == 0) {  // small launch: one block per tile, linear (row-major / packed lower) order
     if (lower) {
       unsigned r = (unsigned)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
@@ -187,14 +187,14 @@ __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower
 
 template <int ALAY, int BLAY, int TM, int TN>
 __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 4))) void gemm_f64_kernel(const GemmDesc g, int tiles_m, int tiles_n,
-                                                                 unsigned nsuper) {
+                                                                 unsigned nsuper, unsigned bid0) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   typedef Tile<ALAY, BM> TA;
   typedef Tile<BLAY, BN> TB;
   __shared__ __attribute__((aligned(16))) double smem[2 * (TA::ELEMS + TB::ELEMS)];
 
   int bi, bj;
-  if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bi, bj)) return;
+  if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bid0, bi, bj)) return;
   const int i0 = bi * BM, j0 = bj * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
@@ -417,6 +417,34 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
   }
 }
 
+// Is slot `within` (0..63) of super-tile st a live (non-empty, on-or-below-diagonal) tile?  Host mirror
+// of block_coords' super-tile mapping.
+bool tile_live(unsigned st, unsigned within, int tiles_m, int tiles_n, int lower) {
+  unsigned sr, sc;
+  if (lower) {
+    sr = (unsigned)((sqrt(8.0 * (double)st + 1.0) - 1.0) * 0.5);
+    while ((sr + 1) * (sr + 2) / 2 <= st) ++sr;
+    while (sr * (sr + 1) / 2 > st) --sr;
+    sc = st - sr * (sr + 1) / 2;
+  } else {
+    const unsigned stc = (tiles_n + 7) / 8;
+    sr = st / stc;
+    sc = (st % stc + sr) % stc;
+  }
+  const int bi = (int)(sr * 8 + (within >> 3)), bj = (int)(sc * 8 + (within & 7));
+  return bi < tiles_m && bj < tiles_n && (!lower || bj <= bi);
+}
+
+constexpr unsigned TAIL_DYN_LDS = 32768;   // 64 KiB static + 32 KiB: two workgroups no longer fit in a CU's 160 KiB
+
+bool tail_split_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("GPX_GEMM_TAIL");   // development switch: 0 disables the separate tail launch
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on;
+}
+
 template <int TM, int TN>
 int launch_cfg(hipStream_t s, const GemmDesc& g) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -437,14 +465,44 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     nsuper = 0;
     grid = dim3((unsigned)ntiles);
   }
-  if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
-    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
-  else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
-    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
-  else if (g.a_lay == GPX_LAY_RC && g.b_lay == GPX_LAY_RC)
-    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
-  else
-    hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), grid, block, 0, s, g, tm, tn, nsuper);
+  auto launch = [&](dim3 gr, unsigned dyn, unsigned bid0) {
+    if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0);
+    else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0);
+    else if (g.a_lay == GPX_LAY_RC && g.b_lay == GPX_LAY_RC)
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0);
+    else
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0);
+  };
+  // Tail of a multi-round launch.  Workgroups are dispatched in id order, 512 live ones per round of
+  // the chip.  When the last round(s) hold few live tiles, the slots they land in are the
+  // two halves of the CUs that finish first, so the tail runs two workgroups per CU on a few CUs --
+  // at half speed each, the fp64 MFMA pipe being shared -- while the other CUs idle (measured: a
+  // 32-tile tail cost 0.43 ms against 0.16 ms for the same tiles one per CU).  Such a tail is
+  // launched separately with enough dynamic LDS that only ONE workgroup fits per CU.
+  unsigned main_ids = grid.x;
+  const long rem = ntiles % 512;   // live tiles beyond the last full round
+  if (nsuper != 0 && TM * TN >= 16 && rem > 0 && rem <= 256 && tail_split_enabled()) {
+    // whole trailing 512-id chunks (8 super-tiles) only: a finer cut was measured and lost -- where the
+    // main part does not end on a chunk boundary its workgroups do not finish together, and the tail
+    // overlaps with them better inside one launch
+    long live = 0;
+    unsigned chunk = grid.x / 512;
+    while (chunk > 1 && live < rem) {
+      --chunk;
+      for (unsigned x = 0; x < 8; ++x)
+        for (unsigned within = 0; within < 64; ++within)
+          if (chunk * 8 + x < nsuper && tile_live(chunk * 8 + x, within, tm, tn, g.c_lower)) ++live;
+    }
+    if (live == rem) main_ids = chunk * 512;
+  }
+  if (main_ids == grid.x) {
+    launch(grid, 0, 0);
+  } else {
+    launch(dim3(main_ids), 0, 0);
+    launch(dim3(grid.x - main_ids), TAIL_DYN_LDS, main_ids);
+  }
   GPX_HIP(hipGetLastError());
   return 0;
 }

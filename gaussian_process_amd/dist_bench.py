@@ -35,7 +35,8 @@ def main(args, rank, local_rank, world):
     from .datasets import synthetic_ard
     n, m, d = args.n, args.m, 8
     X, y, Xs, beta = synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
-    gp = DistributedGP(GpuOps(rt), dist, rank, world, block=getattr(args, "block", 0) or {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024))
+    gp = DistributedGP(GpuOps(rt), dist, rank, world, block=getattr(args, "block", 0) or {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024),
+                       row_chunk=int(os.environ.get("GPX_ROW_CHUNK", "0")) or None)   # env: development override
     sigma, noise = 1.0, 0.1
 
     def step(marks):
@@ -96,8 +97,8 @@ def main(args, rank, local_rank, world):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "synthetic ARD regression n=%d d=8 m=%d, noise 0.1 (BASELINE configs[3])" % (n, m),
-                       "parallelism": "block-column-cyclic x%d, block %d, panel broadcasts (%s), look-ahead 1"
-                                      % (world, gp.block, backend),
+                       "parallelism": "block-column-cyclic x%d, block %d, panel broadcasts (%s) in pieces of %d rows, look-ahead 1"
+                                      % (world, gp.block, backend, gp.row_chunk),
                        "step": "gram + potrf + alpha/LML + predict + LML gradient (block columns of Ky^-1 per owner)"},
             "fit_predict_wall_s": round(ms / 1e3, 4),
             "fit_predict_without_gradient_s": round(sum(stages[k] for k in names[:4]) / 1e3, 4),

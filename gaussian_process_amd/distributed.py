@@ -137,11 +137,19 @@ class GpuOps:
 class DistributedGP:
     """Exact GP regression over the ranks of a torch.distributed process group."""
 
-    def __init__(self, ops, dist, rank, world, block=2048, group=None, update_k=2048, grad_block=None):
+    def __init__(self, ops, dist, rank, world, block=2048, group=None, update_k=2048, grad_block=None,
+                 row_chunk=None):
         assert block % _lib.GPX_NB == 0, "block must be a multiple of 128"
         self.ops, self.dist, self.rank, self.world, self.block, self.group = ops, dist, rank, world, block, group
         self.torch = ops.torch
         self.update_k = update_k          # K the delayed trailing updates aim for (see potrf)
+        # Rows per piece of a panel broadcast (absolute row grid, a multiple of the block width): the
+        # owner of the next panel starts on a piece as soon as it has arrived and sends its own piece
+        # on at once, so the factorisation chain carries one piece per step, not a whole panel.
+        if row_chunk is None:
+            row_chunk = max(block, 8192 if world >= 4 else 16384)
+        assert row_chunk % block == 0, "row_chunk must be a multiple of block"
+        self.row_chunk = row_chunk
         self.grad_block = grad_block or (2048 if world <= 2 else 1024)   # column width of the gradient's own partition
         self._gloo = dist.get_backend(group) == "gloo"
         self.n = 0
@@ -240,34 +248,81 @@ class DistributedGP:
             self.ops.gram(self.kind, self.sigma, self.beta, Xv[k0:], Xv[k0:k0 + kb],
                           self.A[k0:self.n, k0:k0 + kb], self.noise)
 
-    def _factor_panel(self, k, k0, kb, stg, Pprev=None, kprev0=0):
-        """Owner side of step k: (look-ahead: first bring the column up to date with panel k-1,
-        given as Pprev,) potrf of the diagonal block, TRSM of the rows below, pack.  With a previous
-        panel the diagonal block is updated first and factored on the side stream while the main
-        stream updates the rows below it."""
-        n, ops = self.n, self.ops
-        Akk = self.A[k0:k0 + kb, k0:k0 + kb]
-        dk = self._dinv_slice(k0, kb)
-        if Pprev is None:
-            ops.potrf_async(Akk, dk, self.info, k0)
-        else:
-            top = Pprev[k0 - kprev0: k0 - kprev0 + kb]
-            ops.gemm(0, 1, kb, kb, Pprev.shape[1], -1.0, top, top, 1.0, Akk)
-            ops.side_begin()
-            ops.potrf_async(Akk, dk, self.info, k0)
-            token = ops.side_end()
-            if k0 + kb < n:
-                ops.gemm(0, 1, n - k0 - kb, kb, Pprev.shape[1], -1.0, Pprev[k0 - kprev0 + kb:], top, 1.0,
-                         self.A[k0 + kb:n, k0:k0 + kb])
-            ops.side_join(token)
-        if k0 + kb < n:
-            ops.trsm_right(self.A[k0 + kb:n, k0:k0 + kb], Akk, dk)
-        nk = n - k0
-        stg[: nk * kb].view(nk, kb).copy_(self.A[k0:n, k0:k0 + kb])
-        stg[nk * kb: nk * kb + dk.numel()].copy_(dk)
+    def _row_chunks(self, k0):
+        """Row ranges [r0, r1) of panel k (rows k0..n) on the absolute row_chunk grid."""
+        n, rc = self.n, self.row_chunk
+        cuts = [k0] + list(range((k0 // rc + 1) * rc, n, rc)) + [n]
+        return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
 
     def _panel_len(self, k0, kb):
         return (self.n - k0) * kb + self._dinv_slice(k0, kb).numel()
+
+    def _send_panel(self, k, k0, kb, owner, produce=None):
+        """Broadcast panel k (in stg[k % 2]) piece by piece, the diagonal-block inverses last; every
+        rank issues the same sequence of collectives.  On the owner `produce(r0, r1)` computes and
+        packs the rows [r0, r1) right before they are sent.  Returns [(last row + 1, handle), ...]."""
+        stg = self.stg[k % 2]
+        nk = self.n - k0
+        handles = []
+        for r0, r1 in self._row_chunks(k0):
+            if produce is not None:
+                produce(r0, r1)
+            handles.append((r1, self._bcast(stg[(r0 - k0) * kb:(r1 - k0) * kb], owner, async_op=True)))
+        dlen = self._dinv_slice(k0, kb).numel()
+        handles.append((None, self._bcast(stg[nk * kb: nk * kb + dlen], owner, async_op=True)))
+        return handles
+
+    def _producer(self, k, k0, kb, prev=None):
+        """Owner side of panel k as a per-piece callback for _send_panel.  prev = (Pprev, kprev0,
+        handles of panel k-1) or None for the first panel.  First piece: (look-ahead: bring the
+        diagonal block up to date with panel k-1,) potrf of the diagonal block -- on the side stream
+        while the main stream updates the rows below it --, then per piece: update with panel k-1,
+        TRSM against the diagonal block, pack.  A piece only waits for the piece of panel k-1 that
+        holds the same rows."""
+        n, ops = self.n, self.ops
+        stg = self.stg[k % 2]
+        Akk = self.A[k0:k0 + kb, k0:k0 + kb]
+        dk = self._dinv_slice(k0, kb)
+        state = {"arrived": 0}
+
+        def wait_rows(r1):
+            """Make the main stream wait for the pieces of panel k-1 up to the one holding row r1 - 1."""
+            if prev is None:
+                return
+            hs, i = prev[2], state["arrived"]
+            while i < len(hs) and hs[i][0] is not None and (i == 0 or hs[i - 1][0] < r1):
+                hs[i][1].wait()
+                i += 1
+            state["arrived"] = i
+
+        def produce(r0, r1):
+            wait_rows(r1)
+            first = r0 == k0
+            lo = k0 + kb if first else r0
+            token = None
+            if prev is not None:
+                Pp, kp0 = prev[0], prev[1]
+                top = Pp[k0 - kp0: k0 - kp0 + kb]
+                if first:
+                    ops.gemm(0, 1, kb, kb, Pp.shape[1], -1.0, top, top, 1.0, Akk)
+                    ops.side_begin()
+                    ops.potrf_async(Akk, dk, self.info, k0)
+                    token = ops.side_end()
+                if r1 > lo:
+                    ops.gemm(0, 1, r1 - lo, kb, Pp.shape[1], -1.0, Pp[lo - kp0: r1 - kp0], top, 1.0,
+                             self.A[lo:r1, k0:k0 + kb])
+                if token is not None:
+                    ops.side_join(token)
+            elif first:
+                ops.potrf_async(Akk, dk, self.info, k0)
+            if r1 > lo:
+                ops.trsm_right(self.A[lo:r1, k0:k0 + kb], Akk, dk)
+            stg[(r0 - k0) * kb:(r1 - k0) * kb].view(r1 - r0, kb).copy_(self.A[r0:r1, k0:k0 + kb])
+            if first:
+                nk = n - k0
+                stg[nk * kb: nk * kb + dk.numel()].copy_(dk)
+
+        return produce
 
     def _apply_filed(self, j0, jb, c0, c1):
         """A[j0:, J] -= A[j0:, c0:c1] A[J, c0:c1]^T: the panels filed in columns [c0, c1) applied to
@@ -279,36 +334,40 @@ class DistributedGP:
                       self.A[j0:n, j0:j0 + jb])
 
     def potrf(self):
-        """Distributed right-looking Cholesky with DELAYED trailing updates.  Every rank files every
-        panel into its own buffer, so the panels a block column still has to absorb sit side by side
-        in A and are applied together: one GEMM with K = (number of pending panels) x block instead
-        of one short-K GEMM per panel (K = block is 15-20 % slower on the MFMA kernel and rewrites
-        the column every step).  A column is forced up to date one step before it becomes the
-        look-ahead column, so the critical chain only ever applies the newest panel."""
+        """Distributed right-looking Cholesky with DELAYED trailing updates and a row-pipelined
+        panel chain.  Every rank files every panel into its own buffer, so the panels a block column
+        still has to absorb sit side by side in A and are applied together: one GEMM with
+        K = (number of pending panels) x block instead of one short-K GEMM per panel (K = block is
+        15-20 % slower on the MFMA kernel and rewrites the column every step).  A column is forced up
+        to date one step before it becomes the look-ahead column, so the critical chain only ever
+        applies the newest panel -- and it does so piece by piece (row_chunk rows): the owner of panel
+        k+1 updates, solves and sends on the rows of a piece as soon as that piece of panel k is in,
+        so a panel's broadcast overlaps the next panel's factorisation instead of preceding it."""
         ops, t, n, b = self.ops, self.torch, self.n, self.block
         blocks = self._blocks()
-        stg = self.stg
         self.info.zero_()
         group = max(1, self.update_k // b)                # panels per delayed update
         applied = {j: 0 for j, _, _ in blocks}            # first panel column NOT yet applied to column j
         k, k0, kb = blocks[0]
-        if owner_of(0, self.world) == self.rank:
-            self._factor_panel(0, k0, kb, stg[0])
-        work = self._bcast(stg[0][: self._panel_len(k0, kb)], owner_of(0, self.world), async_op=True)
+        o0 = owner_of(0, self.world)
+        handles = self._send_panel(0, k0, kb, o0, self._producer(0, k0, kb) if o0 == self.rank else None)
         for k, k0, kb in blocks:
-            work.wait()
-            cur = stg[k % 2]
+            cur = self.stg[k % 2]
             nk = n - k0
             Pk = cur[: nk * kb].view(nk, kb)
             mine = owner_of(k, self.world) == self.rank
+            nxt = None
             if k + 1 < len(blocks):
                 k1, k10, k1b = blocks[k + 1]
                 o1 = owner_of(k1, self.world)
+                produce = None
                 if o1 == self.rank:  # look-ahead: bring panel k+1 up to date, factor it, send it
                     self._apply_filed(k10, k1b, applied[k1], k0)      # older panels (normally none)
-                    self._factor_panel(k1, k10, k1b, stg[k1 % 2], Pk, k0)
+                    produce = self._producer(k1, k10, k1b, (Pk, k0, handles))
                     applied[k1] = k0 + kb
-                work = self._bcast(stg[k1 % 2][: self._panel_len(k10, k1b)], o1, async_op=True)
+                nxt = self._send_panel(k1, k10, k1b, o1, produce)
+            for _, h in handles:
+                h.wait()
             if not mine:  # file panel k (and its diagonal inverses) so every rank ends with all of L
                 self.A[k0:n, k0:k0 + kb].copy_(Pk)
                 dk = self._dinv_slice(k0, kb)
@@ -320,6 +379,7 @@ class DistributedGP:
                 if j == k + 2 or pending >= group:
                     self._apply_filed(j0, jb, applied[j], k0 + kb)
                     applied[j] = k0 + kb
+            handles = nxt
         # LAPACK info: smallest failing leading minor over all ranks (0 = success)
         big = 2 ** 30
         loc = int(self.info[0].item())

@@ -50,7 +50,7 @@ def worker(rank, world, port, case, q):
             ops = NumpyOps()
         host = lambda x: x.detach().cpu().numpy()
         gp = DistributedGP(ops, dist, rank, world, block=block, update_k=case.get("update_k", 2048),
-                           grad_block=case.get("grad_block", 256))
+                           grad_block=case.get("grad_block", 256), row_chunk=case.get("row_chunk"))
         out = {"rank": rank}
         if case.get("estimator"):
             # the reference's estimator interface over the ranks (distributed_regression.py)
@@ -58,7 +58,8 @@ def worker(rank, world, port, case, q):
             from gaussian_process_amd.distributed_regression import DistributedGaussianProcessRegression as DGPR
             if not case.get("gpu"):
                 DGPR.ops_factory = staticmethod(lambda: ops)
-            DGPR.dist_options = dict(block=block, update_k=case.get("update_k", 2048), grad_block=256)
+            DGPR.dist_options = dict(block=block, update_k=case.get("update_k", 2048), grad_block=256,
+                                     row_chunk=case.get("row_chunk"))
             cov = ARD(sigma=sigma, beta=beta.copy()) if kind == "ard" else RBF(sigma=sigma, beta=float(beta[0]))
             est = DGPR(cov, sigma=noise)
             est.fit(X, y)

@@ -19,10 +19,12 @@ CASES = [
     dict(n=385, m=7, d=1, block=128, kind="rbf"),       # odd n: last block is a single row
     dict(n=100, m=5, d=2, block=128, kind="ard"),       # one block: rank 1 owns nothing
     dict(n=1500, m=9, d=2, block=128, kind="ard", update_k=384),   # delayed updates in groups of 3 panels
+    dict(n=1500, m=9, d=2, block=128, kind="ard", update_k=384, row_chunk=256),   # panels sent in row pieces
+    dict(n=1100, m=6, d=3, block=256, kind="ard", row_chunk=256),  # piece = block, ragged last piece
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_b%d_%s_u%d" % (c["n"], c["block"], c["kind"], c.get("update_k", 2048)))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_b%d_%s_u%d_r%s" % (c["n"], c["block"], c["kind"], c.get("update_k", 2048), c.get("row_chunk")))
 def test_world2_matches_oracle(case):
     for o in _run(2, case):
         assert o["shapes"] == ((case["m"],), (case["m"], case["m"]))
@@ -32,7 +34,7 @@ def test_world2_matches_oracle(case):
 
 
 def test_world3_matches_oracle():
-    for o in _run(3, dict(n=900, m=20, d=4, block=128, kind="ard", update_k=256)):
+    for o in _run(3, dict(n=900, m=20, d=4, block=128, kind="ard", update_k=256, row_chunk=384)):
         assert o["L"] < 1e-12 and o["lml"] < 1e-11 and o["mean"] < 1e-10 and o["cov"] < 1e-9, o
 
 

@@ -18,6 +18,7 @@ CASES = [
     dict(n=2049, m=64, d=1, block=512, kind="rbf", gpu=True),     # odd n: last block is one row
     dict(n=100, m=5, d=2, block=128, kind="ard", gpu=True),       # one block: rank 1 owns nothing
     dict(n=3000, m=17, d=8, block=128, kind="ard", gpu=True, update_k=512),   # delayed updates, groups of 4
+    dict(n=3000, m=17, d=8, block=256, kind="ard", gpu=True, update_k=512, row_chunk=512),   # panels sent in row pieces
 ]
 
 
@@ -31,7 +32,7 @@ def test_world2_gpu_matches_oracle(case):
 
 
 def test_world3_gpu_matches_oracle():
-    for o in _run(3, dict(n=3000, m=50, d=8, block=256, kind="ard", gpu=True, update_k=512)):
+    for o in _run(3, dict(n=3000, m=50, d=8, block=256, kind="ard", gpu=True, update_k=512, row_chunk=768)):
         assert o["L"] < 1e-12 and o["lml"] < 1e-11 and o["mean"] < 1e-9 and o["cov"] < 1e-9, o
 
 
