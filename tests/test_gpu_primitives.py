@@ -69,6 +69,24 @@ def test_gemm_identity_asymmetric(rt):
     assert np.array_equal(down(rt, dC, n, n), B)
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 17408, 512, 40), (0, 0, 20480, 512, 24), (1, 1, 17000, 500, 17),
+                                         (0, 1, 16512, 16512, 8)])
+def test_gemm_multi_round_launches(rt, ta, tb, M, N, K):
+    """More than 512 tiles: the XCD super-tile mapping, and for the first three shapes a sparse last
+    round (544 / 640 / 532 tiles of 128 x 128) that is launched separately at one workgroup per CU."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    Cm = rng.standard_normal((M, N))
+    dA, dB, dC = up(rt, A), up(rt, B), up(rt, Cm)
+    ok(rt.lib.gpx_gemm(rt.h, ta, tb, M, N, K, -1.0, P(dA), dA.shape[1], P(dB), dB.shape[1], 1.0,
+                       P(dC), dC.shape[1]))
+    ref = Cm - (A.T if ta else A) @ (B.T if tb else B)
+    got = down(rt, dC, M, N)
+    assert relerr(got, ref) < 1e-13
+    assert np.max(np.abs(got - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))   # no tile skipped or done twice
+
+
 # ----------------------------------------------------------------------------- Gram
 @pytest.mark.parametrize("kind,d", [("rbf", 1), ("rbf", 3), ("ard", 2), ("ard", 8), ("ard", 5)])
 @pytest.mark.parametrize("n1,n2", [(1, 1), (15, 50), (129, 257), (300, 300)])
@@ -117,7 +135,7 @@ def test_gram_dtheta_matches_oracle(rt):
 
 
 # ----------------------------------------------------------------------------- Cholesky family
-@pytest.mark.parametrize("n", [1, 2, 15, 100, 128, 129, 255, 300, 1000, 2050])
+@pytest.mark.parametrize("n", [1, 2, 15, 100, 128, 129, 255, 300, 1000, 2050, 4100, 5000])
 def test_potrf_trsm_trtri_lauum(rt, n):
     A = spd(n, n)
     dA = up(rt, A)
