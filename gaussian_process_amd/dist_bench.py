@@ -37,7 +37,8 @@ def main(args, rank, local_rank, world):
     X, y, Xs, beta = synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
     gp = DistributedGP(GpuOps(rt), dist, rank, world, block=getattr(args, "block", 0) or {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024),
                        row_chunk=int(os.environ.get("GPX_ROW_CHUNK", "0")) or None,   # env: development overrides
-                       grad_block=int(os.environ.get("GPX_GRAD_BLOCK", "0")) or None)
+                       grad_block=int(os.environ.get("GPX_GRAD_BLOCK", "0")) or None,
+                       update_k=int(os.environ.get("GPX_UPDATE_K", "0")) or None)
     sigma, noise = 1.0, 0.1
 
     def step(marks):

@@ -137,12 +137,16 @@ class GpuOps:
 class DistributedGP:
     """Exact GP regression over the ranks of a torch.distributed process group."""
 
-    def __init__(self, ops, dist, rank, world, block=2048, group=None, update_k=2048, grad_block=None,
+    def __init__(self, ops, dist, rank, world, block=2048, group=None, update_k=None, grad_block=None,
                  row_chunk=None):
         assert block % _lib.GPX_NB == 0, "block must be a multiple of 128"
         self.ops, self.dist, self.rank, self.world, self.block, self.group = ops, dist, rank, world, block, group
         self.torch = ops.torch
-        self.update_k = update_k          # K the delayed trailing updates aim for (see potrf)
+        # K the delayed trailing updates aim for (see potrf).  Longer K is cheaper per flop (world 1,
+        # block 512: potrf 1.77 s at K = 1024, 1.67 at 2048, 1.63 at 4096, 1.62 at 8192) but one such GEMM
+        # must stay short next to a factorisation step, because the next panel's chain queues behind
+        # it on the same stream: 8192 on one rank, 4096 on two, 2048 beyond.
+        self.update_k = update_k or {1: 8192, 2: 4096}.get(world, 2048)
         # Rows per piece of a panel broadcast (absolute row grid, a multiple of the block width): the
         # owner of the next panel starts on a piece as soon as it has arrived and sends its own piece
         # on at once, so the factorisation chain carries one piece per step, not a whole panel.
