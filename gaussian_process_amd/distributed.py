@@ -380,11 +380,15 @@ class DistributedGP:
                 self.A[k0:n, k0:k0 + kb].copy_(Pk)
                 dk = self._dinv_slice(k0, kb)
                 dk.copy_(cur[nk * kb: nk * kb + dk.numel()])
+            # The rank that factors panel k+2 next step enqueues only that column's catch-up now: its
+            # other updates would sit in the stream ahead of the chain it is about to run, and lose
+            # nothing by waiting one step (they come back with a longer K).
+            chain_next = k + 2 < len(blocks) and owner_of(k + 2, self.world) == self.rank
             for j, j0, jb in blocks[k + 2:]:
                 if owner_of(j, self.world) != self.rank:
                     continue
                 pending = (k0 + kb - applied[j] + b - 1) // b
-                if j == k + 2 or pending >= group:
+                if j == k + 2 or (pending >= group and not chain_next):
                     self._apply_filed(j0, jb, applied[j], k0 + kb)
                     applied[j] = k0 + kb
             handles = nxt
