@@ -58,6 +58,25 @@ __global__ __launch_bounds__(THREADS) void ep_site_kernel(int n, int i, int t, c
   const int tid = threadIdx.x;
   const int tpad = (t + 15) & ~15;
 
+  // ---- loads that do not depend on anything computed here go first, so their latency overlaps ----
+  const int r = blockIdx.x * ROWS + (tid >> 3);
+  const int sub = tid & 7;
+  double sig_ii = 0.0, mu_i = 0.0, yi = 0.0, tau_i = 0.0, nu_i = 0.0;
+  if (tid == 0) {
+    sig_ii = Sigma[(long)i * ld + i];
+    mu_i = in.mu[i];
+    yi = y[i];
+    tau_i = in.tau[i];
+    nu_i = in.nu[i];
+  }
+  double base = 0.0, mu_r = 0.0, tau_r = 0.0, nu_r = 0.0;
+  if (r < n && sub == 0) {
+    base = r <= i ? Sigma[(long)i * ld + r] : Sigma[(long)r * ld + i];   // column i of the symmetric Sigma_0
+    mu_r = in.mu[r];
+    tau_r = in.tau[r];
+    nu_r = in.nu[r];
+  }
+
   // ---- scalars of site i (repeated identically in every workgroup) ----
   double part = 0.0;
   if (tid < EPB) {
@@ -75,10 +94,7 @@ __global__ __launch_bounds__(THREADS) void ep_site_kernel(int n, int i, int t, c
   if (tid == 0) {
     double corr = 0.0;
     for (int q = 0; q < THREADS / 64; ++q) corr += wred[q];
-    const double sii = Sigma[(long)i * ld + i] + corr;
-    const double mu_i = in.mu[i];
-    const double yi = y[i];
-    const double tau_i = in.tau[i], nu_i = in.nu[i];
+    const double sii = sig_ii + corr;
     const double tau_cav = 1.0 / sii - tau_i;
     const double nu_cav = mu_i / sii - nu_i;
     const double dom = tau_cav * tau_cav + tau_cav;
@@ -97,30 +113,38 @@ __global__ __launch_bounds__(THREADS) void ep_site_kernel(int n, int i, int t, c
     sc[3] = nu_new;
     if (blockIdx.x == 0) coef[t] = cf;
   }
-  __syncthreads();
 
-  // ---- rows of the column s_t, the appended columns and the state ----
-  const int r = blockIdx.x * ROWS + (tid >> 3);
-  const int sub = tid & 7;
+  // ---- rows of the column s_t (needs only w, available since the barrier above) ----
   double acc = 0.0;
   if (r < n) {
     const double* srow = Sbuf + (long)r * EPB;
-    for (int j = 2 * sub; j < tpad; j += 16) {
-      const v2d sv = *reinterpret_cast<const v2d*>(srow + j);
-      acc = fma(sv.x, w[j], acc);
-      acc = fma(sv.y, w[j + 1], acc);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int j = 2 * sub;
+    for (; j + 48 < tpad; j += 64) {   // four independent 16-byte loads in flight
+      const v2d s0 = *reinterpret_cast<const v2d*>(srow + j);
+      const v2d s1 = *reinterpret_cast<const v2d*>(srow + j + 16);
+      const v2d s2 = *reinterpret_cast<const v2d*>(srow + j + 32);
+      const v2d s3 = *reinterpret_cast<const v2d*>(srow + j + 48);
+      a0 = fma(s0.y, w[j + 1], fma(s0.x, w[j], a0));
+      a1 = fma(s1.y, w[j + 17], fma(s1.x, w[j + 16], a1));
+      a2 = fma(s2.y, w[j + 33], fma(s2.x, w[j + 32], a2));
+      a3 = fma(s3.y, w[j + 49], fma(s3.x, w[j + 48], a3));
     }
+    for (; j < tpad; j += 16) {
+      const v2d sv = *reinterpret_cast<const v2d*>(srow + j);
+      a0 = fma(sv.y, w[j + 1], fma(sv.x, w[j], a0));
+    }
+    acc = (a0 + a1) + (a2 + a3);
   }
   acc = reduce8(acc);
+  __syncthreads();   // sc[] from thread 0
   if (r < n && sub == 0) {
-    // column i of the symmetric Sigma_0 from its lower triangle
-    const double base = r <= i ? Sigma[(long)i * ld + r] : Sigma[(long)r * ld + i];
     const double col = base + acc;
     Sbuf[(long)r * EPB + t] = col;
     Tbuf[(long)r * EPB + t] = sc[0] * col;
-    out.mu[r] = fma(sc[1], col, in.mu[r]);
-    out.tau[r] = r == i ? sc[2] : in.tau[r];
-    out.nu[r] = r == i ? sc[3] : in.nu[r];
+    out.mu[r] = fma(sc[1], col, mu_r);
+    out.tau[r] = r == i ? sc[2] : tau_r;
+    out.nu[r] = r == i ? sc[3] : nu_r;
   }
 }
 
