@@ -55,7 +55,7 @@ class GaussianProcessDistillation(GaussianProcessExpectationPropagation):
 
     def log_marginal_likelihood(self, eps=1e-7, splitted_terms=False):
         n = self.n
-        dS = np.diag(self.Sigma)
+        dS = self._diag_Sigma()
         tau_cav = 1 / dS - self.tau_tilde
         nu_cav = self.mu / dS - self.nu_tilde
         t0 = -np.log(np.trace(self.L))

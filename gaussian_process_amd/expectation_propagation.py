@@ -41,8 +41,9 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
     def fit(self, X, y):
         self.Xtr, self.ytr = check_X_y(X, y)
         self.n, self.dim = self.Xtr.shape
-        K = self.cov(self.Xtr).K
-        self._ep(K)
+        # K + eps I built on the device and left there (expectation_propagation.py:19, 38): the host copies
+        # of K, Sigma and L that the reference keeps as attributes are downloaded only if somebody reads them
+        self._ep(self.cov.device_gram(np.asarray(self.Xtr, dtype=np.float64), diag_add=eps))
 
     def refit(self):
         self.fit(self.Xtr, self.ytr)
@@ -99,8 +100,15 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
             nu_fixed = np.array([])
             tau_fixed = np.array([])
 
-        n = K.shape[0]
-        K = np.asarray(K, dtype=np.float64) + eps * np.eye(n)
+        rt = runtime()
+        rt.bind_stream()
+        if isinstance(K, np.ndarray):          # host matrix (reference call convention): add the jitter, upload
+            n = K.shape[0]
+            K = np.asarray(K, dtype=np.float64) + eps * np.eye(n)
+            Kd, self._K_host = rt.upload_matrix(K), K
+        else:                                   # device matrix from device_gram(), jitter already on its diagonal
+            n = K.shape[0]
+            Kd, self._K_host = K, None
         frozen = np.zeros(n, dtype=bool)
         frozen[fix_index] = True
         tau = np.zeros(n)
@@ -109,9 +117,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         nu[fix_index] = nu_fixed
         y = np.asarray(self.ytr, dtype=np.float64)
 
-        rt = runtime()
-        rt.bind_stream()
-        dv = dict(rt=rt, n=n, K=rt.upload_matrix(K), B=rt.matrix(n, n), V=rt.matrix(n, n),
+        dv = dict(rt=rt, n=n, K=Kd, B=rt.matrix(n, n), V=rt.matrix(n, n),
                   Sigma=rt.matrix(n, n), dinv=rt.dinv(n), tau=rt.upload_vector(tau), nu=rt.upload_vector(nu),
                   s=rt.vector(n), mu=rt.vector(n), y=rt.upload_vector(y),
                   work=rt.vector(int(rt.lib.gpx_ep_sweep_work_elems(n))))
@@ -129,19 +135,47 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
             nu = rt.download(dv["nu"][:n]).copy()
             if np.sum((tau_prev - tau) ** 2) < eps and np.sum((nu_prev - nu) ** 2) < eps:
                 break
-        Sigma = np.ascontiguousarray(rt.download(dv["Sigma"][:n, :n]))
-        mu = rt.download(dv["mu"][:n]).copy()
-
         self.nu_tilde = nu
         self.tau_tilde = tau
-        self.mu = mu
-        self.Sigma = Sigma
-        self.K = K
+        self.mu = rt.download(dv["mu"][:n]).copy()
         self.S = np.sqrt(tau).reshape(-1, 1)
         self._dv = dv
         self._L_host = None
-        w = self._solve_vec(dv, self.S.ravel() * (K @ nu), trans=0)
+        self._Sigma_host = None
+        w = self._solve_vec(dv, self.S.ravel() * self._K_times(nu), trans=0)
         self.z = self.S.ravel() * self._solve_vec(dv, w, trans=1)
+
+    def _K_times(self, v):
+        """K v on the device (K resident since the fit)."""
+        dv = self._dv
+        rt, n = dv["rt"], dv["n"]
+        rt.bind_stream()
+        x, out = rt.upload_vector(np.ascontiguousarray(v, dtype=np.float64)), rt.vector(n)
+        _lib.check(rt.lib.gpx_gemv(rt.h, 0, n, n, ptr(dv["K"]), dv["K"].shape[1], ptr(x), ptr(out)), "gpx_gemv")
+        return rt.download(out[:n]).copy()
+
+    def _diag_Sigma(self):
+        dv = self._dv
+        rt, n = dv["rt"], dv["n"]
+        rt.bind_stream()
+        out = rt.vector(n)
+        _lib.check(rt.lib.gpx_diag(rt.h, n, ptr(dv["Sigma"]), dv["Sigma"].shape[1], ptr(out)), "gpx_diag")
+        return rt.download(out[:n]).copy()
+
+    # host views of the device state, as the reference's attributes; downloaded on first use
+    @property
+    def K(self):
+        if self._K_host is None:
+            dv = self._dv
+            self._K_host = np.ascontiguousarray(dv["rt"].download(dv["K"][: dv["n"], : dv["n"]]))
+        return self._K_host
+
+    @property
+    def Sigma(self):
+        if self._Sigma_host is None:
+            dv = self._dv
+            self._Sigma_host = np.ascontiguousarray(dv["rt"].download(dv["Sigma"][: dv["n"], : dv["n"]]))
+        return self._Sigma_host
 
     @property
     def L(self):
@@ -170,7 +204,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         return np.sign(self.decision_function(X) - 0.5)
 
     def log_marginal_likelihood(self, splitted_terms=False):
-        dS = np.diag(self.Sigma)
+        dS = self._diag_Sigma()
         tau_cav = 1 / dS - self.tau_tilde
         nu_cav = self.mu / dS - self.nu_tilde
         dv = self._dv
@@ -180,7 +214,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
                    "gpx_logdet")
         t0 = -ld.value
         t1 = 0.5 * np.sum(np.log(1 + self.tau_tilde / tau_cav))
-        Knu = self.K @ self.nu_tilde
+        Knu = self._K_times(self.nu_tilde)
         t2 = 0.5 * self.nu_tilde.dot(Knu)
         w = self._solve_vec(dv, self.S.ravel() * Knu, trans=0)
         t3 = -0.5 * w.dot(w)

@@ -69,6 +69,22 @@ class _StationaryKernel(BaseEstimator):
         return (rt.download(K[:n1, :n2]), rt.download(dsig[:n1, :n2]),
                 rt.download(dbeta[:, :n1, :n2]))
 
+    def device_gram(self, X, diag_add=0.0):
+        """K(X, X) + diag_add * I as a device-resident matrix (full, symmetric): what the estimators use
+        when the host copy that ``__call__`` returns is not needed.  Same argument checks as
+        ``__call__``; no derivative planes, nothing crosses to the host."""
+        X = _as_2d(X, "X1")
+        rt = runtime()
+        rt.bind_stream()
+        n, dim = X.shape
+        kind, sigma, beta = self.gram_params(dim)
+        _, beta_p = _keep = _lib.host_doubles(beta)
+        dX = rt.upload_matrix(X)
+        K = rt.matrix(n, n)
+        _lib.check(rt.lib.gpx_gram(rt.h, kind, ptr(dX), n, dX.shape[1], ptr(dX), n, dX.shape[1], dim, sigma, beta_p,
+                                   float(diag_add), ptr(K), K.shape[1], _lib.GPX_FULL), "gpx_gram")
+        return K
+
     def _call(self, X1, X2, diag, dim_check=None):
         X1 = _as_2d(X1, "X1")
         X2 = X1 if X2 is None else _as_2d(X2, "X2")

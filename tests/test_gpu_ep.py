@@ -45,6 +45,12 @@ def test_ep_notebook_fit_score():
     ep.fit(g["Xtr"], g["ytr"])
     assert abs(ep.score(g["Xte"], g["yte"]) - 0.92) < 1e-12
     assert abs(ep.log_marginal_likelihood() - float(g["lml"])) < 1e-4
+    # fit() keeps K and Sigma on the device; the reference's host attributes appear on first use
+    n = len(g["ytr"])
+    assert ep._K_host is None and ep._Sigma_host is None
+    assert relerr(ep.K, g["K"] + 1e-8 * np.eye(n)) < 1e-13
+    assert ep.Sigma.shape == (n, n) and np.array_equal(np.diag(ep.Sigma), ep._diag_Sigma())
+    assert relerr(np.diag(ep.L), g["diagL"]) < 1e-4
 
 
 @pytest.mark.parametrize("n", [37, 200, 515])
