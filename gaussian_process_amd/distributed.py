@@ -11,16 +11,18 @@ Layout and algorithm (realised 1-D for round 1):
     every trailing update to it;
   * step k: the owner factors the diagonal block (``gpx_potrf_async``), solves the panel below it
     (``gpx_trsm_right``), packs panel k (+ its 128x128 diagonal-block inverses) into a contiguous
-    staging buffer and broadcasts it; every rank then updates its own block columns j > k with
-    ``A[j0:, j] -= P[j0:, :] P[j0:j0+b, :]^T`` (one MFMA GEMM each) and files the panel into its
-    buffer, so after the last step EVERY rank holds the complete factor L;
-  * look-ahead: the owner of panel k+1 updates and factors it first and posts its broadcast
-    (async, RCCL's own stream) before the bulk updates of step k are enqueued, so the transfer
-    and the panel factorisation hide under the other ranks' GEMMs;
+    staging buffer and broadcasts it in row pieces; every rank files the panel into its buffer, so
+    after the last step EVERY rank holds the complete factor L, and applies the filed panels to its
+    own block columns j > k a few at a time, ``A[j0:, j] -= A[j0:, c0:c1] A[j, c0:c1]^T`` (one MFMA
+    GEMM with a long K instead of one per panel);
+  * look-ahead: the owner of panel k+1 brings its column up to date with panel k piece by piece as
+    the pieces arrive, factors it and posts its own pieces (async, RCCL's own stream) before the bulk
+    updates of step k are enqueued, so the transfers and the panel factorisation hide under the
+    other ranks' GEMMs;
   * solves after the factorisation are split by right-hand-side column: rank r computes
     ``V[:, cols_r] = L^-1 k*(:, cols_r)``; V is all-gathered for the ``V^T V`` block rows.
-Communication per step: one broadcast of (n - k*block) x block doubles (the whole lower triangle
-once per rank over the factorisation, 17 GB at n = 65536) -- no other data-path collective.
+Communication per step: the broadcasts of one panel, (n - k*block) x block doubles in all (the whole
+lower triangle once per rank over the factorisation, 17 GB at n = 65536) -- no other data-path collective.
 """
 import ctypes as C
 
