@@ -17,7 +17,7 @@
  *     16-byte vector accesses); violations return GPX_EINVAL, they never fault;
  *   - "lower" matrices are referenced in their lower triangle only (row >= col);
  *   - the caller owns every buffer; the library allocates nothing in these calls except
- *     inside gpx_create / gpx_reserve;
+ *     inside gpx_create;
  *   - calls are asynchronous on the handle's stream unless they return a host value
  *     (info, scalars), in which case they synchronise that stream;
  *   - return value: 0 ok; >0 LAPACK-style info (order of the leading minor that is not
