@@ -145,8 +145,34 @@ struct Tile {
 // (idx / 64) * 8 + xcd, so the 64 workgroups resident on one XCD work on one 8 x 8 super-tile
 // (8 A panels + 8 B panels in its private L2) and super-tiles are dealt round-robin over the XCDs
 // (balanced also when the work per tile varies, as with triangular operands).
+// Traversal order of the super-tiles of a full (non-lower) launch.  With a triangular operand the
+// work of a tile depends on its row or column; the heavy ones go first so that the last round of the
+// launch holds only light tiles (longest-processing-time-first), and at any moment all XCDs work on
+// tiles of similar weight.
+enum { ORD_ROWS_SKEWED = 0, ORD_COLS_ASC = 1, ORD_COLS_DESC = 2, ORD_ROWS_DESC = 3 };
+
+__host__ __device__ __forceinline__ void super_coords(unsigned st, int tiles_m, int tiles_n, int order, unsigned& sr,
+                                                      unsigned& sc) {
+  const unsigned stc = (tiles_n + 7) / 8, str_ = (tiles_m + 7) / 8;
+  switch (order) {
+    case ORD_COLS_ASC: sc = st / str_; sr = st % str_; break;
+    case ORD_COLS_DESC: sc = stc - 1 - st / str_; sr = st % str_; break;
+    case ORD_ROWS_DESC: sr = str_ - 1 - st / stc; sc = st % stc; break;
+    default:
+      // skewed columns: with stc a multiple of 8, plain st % stc would hand XCD x the same super-tile
+      // columns on every row; the skew walks every XCD through all columns.
+      sr = st / stc;
+      sc = (st % stc + sr) % stc;
+  }
+}
+
+// Logical tile coordinates of this workgroup.  Blocks id % 8 share an XCD (round-robin dispatch,
+// MI355X_MICROARCH.md): the idx-th block of an XCD takes slot idx % 64 of super-tile
+// (idx / 64) * 8 + xcd, so the 64 workgroups resident on one XCD work on one 8 x 8 super-tile
+// (8 A panels + 8 B panels in its private L2) and super-tiles are dealt round-robin over the XCDs
+// (balanced also when the work per tile varies, as with triangular operands).
 __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower, unsigned nsuper, unsigned bid0,
-                                             int& bi, int& bj) {
+                                             int order, int& bi, int& bj) {
   const unsigned bid = blockIdx.x + bid0;
   if (nsuper == 0) {  // small launch: one block per tile, linear (row-major / packed lower) order
     if (lower) {
@@ -171,12 +197,7 @@ __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower
     while (sr * (sr + 1) / 2 > st) --sr;
     sc = st - sr * (sr + 1) / 2;
   } else {
-    // skewed columns: with stc a multiple of 8, plain st % stc would hand XCD x the same super-tile
-    // columns on every row; when the work per tile depends on the column (triangular B operand)
-    // that unbalances the XCDs by up to 1.5x.  The skew walks every XCD through all columns.
-    const unsigned stc = (tiles_n + 7) / 8;
-    sr = st / stc;
-    sc = (st % stc + sr) % stc;
+    super_coords(st, tiles_m, tiles_n, order, sr, sc);
   }
   bi = (int)(sr * 8 + (within >> 3));
   bj = (int)(sc * 8 + (within & 7));
@@ -187,14 +208,14 @@ __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower
 
 template <int ALAY, int BLAY, int TM, int TN>
 __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 4))) void gemm_f64_kernel(const GemmDesc g, int tiles_m, int tiles_n,
-                                                                 unsigned nsuper, unsigned bid0) {
+                                                                 unsigned nsuper, unsigned bid0, int order) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   typedef Tile<ALAY, BM> TA;
   typedef Tile<BLAY, BN> TB;
   __shared__ __attribute__((aligned(16))) double smem[2 * (TA::ELEMS + TB::ELEMS)];
 
   int bi, bj;
-  if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bid0, bi, bj)) return;
+  if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bid0, order, bi, bj)) return;
   const int i0 = bi * BM, j0 = bj * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
 
 // Is slot `within` (0..63) of super-tile st a live (non-empty, on-or-below-diagonal) tile?  Host mirror
 // of block_coords' super-tile mapping.
-bool tile_live(unsigned st, unsigned within, int tiles_m, int tiles_n, int lower) {
+bool tile_live(unsigned st, unsigned within, int tiles_m, int tiles_n, int lower, int order) {
   unsigned sr, sc;
   if (lower) {
     sr = (unsigned)((sqrt(8.0 * (double)st + 1.0) - 1.0) * 0.5);
@@ -427,9 +448,7 @@ bool tile_live(unsigned st, unsigned within, int tiles_m, int tiles_n, int lower
     while (sr * (sr + 1) / 2 > st) --sr;
     sc = st - sr * (sr + 1) / 2;
   } else {
-    const unsigned stc = (tiles_n + 7) / 8;
-    sr = st / stc;
-    sc = (st % stc + sr) % stc;
+    super_coords(st, tiles_m, tiles_n, order, sr, sc);
   }
   const int bi = (int)(sr * 8 + (within >> 3)), bj = (int)(sc * 8 + (within & 7));
   return bi < tiles_m && bj < tiles_n && (!lower || bj <= bi);
@@ -465,15 +484,22 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     nsuper = 0;
     grid = dim3((unsigned)ntiles);
   }
+  // heavy tiles first (see super_coords): which side is heavy follows from how gemm_f64_kernel clips k
+  int order = ORD_ROWS_SKEWED;
+  static const bool lpt = getenv("GPX_GEMM_LPT") == nullptr || atoi(getenv("GPX_GEMM_LPT")) != 0;   // development switch
+  if (!g.c_lower && lpt) {
+    if (g.b_tri) order = g.b_lay == GPX_LAY_RC ? ORD_COLS_ASC : ORD_COLS_DESC;      // k >= j0  |  k < j0 + BN
+    else if (g.a_tri && g.a_lay == GPX_LAY_KC) order = ORD_ROWS_DESC;               // k < i0 + BM
+  }
   auto launch = [&](dim3 gr, unsigned dyn, unsigned bid0) {
     if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
-      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0);
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
     else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
-      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0);
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
     else if (g.a_lay == GPX_LAY_RC && g.b_lay == GPX_LAY_RC)
-      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0);
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
     else
-      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0);
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
   };
   // Tail of a multi-round launch.  Workgroups are dispatched in id order, 512 live ones per round of
   // the chip.  When the last round(s) hold few live tiles, the slots they land in are the
@@ -493,7 +519,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
       --chunk;
       for (unsigned x = 0; x < 8; ++x)
         for (unsigned within = 0; within < 64; ++within)
-          if (chunk * 8 + x < nsuper && tile_live(chunk * 8 + x, within, tm, tn, g.c_lower)) ++live;
+          if (chunk * 8 + x < nsuper && tile_live(chunk * 8 + x, within, tm, tn, g.c_lower, order)) ++live;
     }
     if (live == rem) main_ids = chunk * 512;
   }
