@@ -49,6 +49,8 @@ SIGNATURES = {
                               _dp, _dp, _hp, _hp]),
     "gpx_gpr_predict": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _dp, _i, _i,
                              _dp, _i, _dp, _dp, _dp, _i, _dp, _i]),
+    "gpx_gpr_predict_inv": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _i, _i, _dp, _dp,
+                                 _i, _dp, _dp, _i, _dp, _i]),
     "gpx_ep_scale": (_i, [C.c_void_p, _i, _dp, _i, _dp, _dp, _i, _dp, _i]),
     "gpx_ep_sweep": (_i, [C.c_void_p, _i, _dp, _i, _dp, _dp, _dp, C.POINTER(C.c_int), _i, _dp]),
     "gpx_ep_sweep_work_elems": (C.c_size_t, [_i]),

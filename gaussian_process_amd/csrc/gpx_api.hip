@@ -626,6 +626,44 @@ int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, in
   return 0;
 }
 
+int gpx_gpr_predict_inv(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
+                        const double* beta_host, double noise, const double* a, const double* W, int ldw,
+                        const double* Xs, int m, int ldxs, double* Ks, double* V, int ldv, double* mean,
+                        double* cov, int ldc, double* var, int full_cov) {
+  GPX_REQUIRE(h != nullptr, "null handle");
+  BetaArg b;
+  int nbeta;
+  GPX_TRY(fill_beta(kind, d, beta_host, b, nbeta));
+  GPX_REQUIRE(n > 0 && m > 0 && X && Xs && a && mean && ldx >= d && ldxs >= d, "gpr_predict_inv: bad arguments");
+  GPX_TRY(check_mat("gpr_predict_inv: W", W, ldw, n));
+  GPX_TRY(check_mat("gpr_predict_inv: Ks", Ks, ldv, m));
+  GPX_TRY(check_mat("gpr_predict_inv: V", V, ldv, m));
+  GPX_REQUIRE(Ks != V, "gpr_predict_inv: Ks and V must be distinct buffers");
+  if (full_cov) GPX_TRY(check_mat("gpr_predict_inv: cov", cov, ldc, m));
+  else GPX_REQUIRE(var != nullptr, "gpr_predict_inv: var is null");
+  DeviceGuard dg(h->device);
+  hipStream_t s = h->stream;
+  // k* = K(Xtr, Xs) (regression.py:33); V = L^-1 k* (regression.py:38) as a triangular multiply by W
+  GPX_TRY(gpx_gram_launch(s, X, n, ldx, Xs, m, ldxs, d, sigma, b, 0.0, Ks, ldv, GPX_FULL));
+  GemmDesc gw = mk(W, ldw, GPX_LAY_KC, Ks, ldv, GPX_LAY_RC, nullptr, 0, V, ldv, n, m, n, 1.0, 0.0);
+  gw.a_tri = 1;
+  GPX_TRY(gpx_gemm_launch(s, gw));
+  // mean = a . V (regression.py:39)
+  GPX_TRY(gpx_gemv_launch(s, 1, n, m, V, ldv, a, mean, h->red, RED_USABLE));
+  if (full_cov) {
+    // cov = K(Xs,Xs) - V^T V + noise I (regression.py:41-44)
+    GPX_TRY(gpx_gram_launch(s, Xs, m, ldxs, Xs, m, ldxs, d, sigma, b, 0.0, cov, ldc, GPX_LOWER));
+    GemmDesc g = mk(V, ldv, GPX_LAY_RC, V, ldv, GPX_LAY_RC, cov, ldc, cov, ldc, m, m, n, -1.0, 1.0);
+    g.c_lower = 1;
+    g.diag_add = noise;
+    GPX_TRY(gpx_gemm_launch(s, g));
+    GPX_TRY(gpx_symmetrize_launch(s, m, cov, ldc));
+  } else {
+    GPX_TRY(gpx_colsumsq_sub_launch(s, n, m, V, ldv, sigma + noise, var, h->red, RED_USABLE));
+  }
+  return 0;
+}
+
 int gpx_ep_scale(gpx_handle* h, int n, const double* K, int ldk, const double* sv, double* B,
                  int ldb, double* SK, int ldsk) {
   GPX_REQUIRE(h != nullptr && K && sv && B && SK, "ep_scale: null argument");

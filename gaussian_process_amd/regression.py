@@ -3,7 +3,8 @@
 Same constructor, methods, attribute names, parameter names/bounds and return shapes as the
 reference class (regression.py:8-76); the arithmetic runs in libgpx:
 
-  predict_with_variance   regression.py:31-44  -> gpx_gpr_lml_grad (factor) + gpx_gpr_predict
+  predict_with_variance   regression.py:31-44  -> gpx_gpr_lml_grad (factor) + gpx_gpr_predict, or
+                                                  gpx_gpr_predict_inv after a gradient evaluation
   log_marginal_likelihood regression.py:46-55  -> gpx_gpr_lml_grad (grad_host = NULL)
   grad_log_marginal_...   regression.py:57-76  -> gpx_gpr_lml_grad (fused LML + gradient)
 
@@ -128,9 +129,8 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
             parts = [self.predict_with_variance(X[i:i + batch], full_cov=False, batch=batch)
                      for i in range(0, m, batch)]
             return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
-        st = self._evaluate(need_grad=False)
-        if not st["has_factor"]:   # the gradient pass overwrote L with L^-1: factor again
-            self._state = None
+        st = getattr(self, "_state", None)
+        if st is None or st["key"] != self._theta_key():
             st = self._evaluate(need_grad=False)
         dv = self._dev
         rt = dv["rt"]
@@ -142,12 +142,22 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         mean = rt.vector(m)
         cov = rt.matrix(m, m) if full_cov else None
         var = None if full_cov else rt.vector(m)
-        rc = rt.lib.gpx_gpr_predict(
-            rt.h, key[0], ptr(dv["X"]), self.n, dv["X"].shape[1], self.dim, key[1], beta_p, key[3],
-            ptr(dv["y"]), ptr(dv["Ky"]), dv["Ky"].shape[1], ptr(dv["dinv"]), ptr(dXs), m, dXs.shape[1],
-            ptr(V), V.shape[1], ptr(dv["vec"]), ptr(mean), ptr(cov) if full_cov else None,
-            cov.shape[1] if full_cov else 0, None if full_cov else ptr(var), 1 if full_cov else 0)
-        _lib.check(rc, "gpx_gpr_predict")
+        if st["has_factor"]:
+            rc = rt.lib.gpx_gpr_predict(
+                rt.h, key[0], ptr(dv["X"]), self.n, dv["X"].shape[1], self.dim, key[1], beta_p, key[3],
+                ptr(dv["y"]), ptr(dv["Ky"]), dv["Ky"].shape[1], ptr(dv["dinv"]), ptr(dXs), m, dXs.shape[1],
+                ptr(V), V.shape[1], ptr(dv["vec"]), ptr(mean), ptr(cov) if full_cov else None,
+                cov.shape[1] if full_cov else 0, None if full_cov else ptr(var), 1 if full_cov else 0)
+            _lib.check(rc, "gpx_gpr_predict")
+        else:
+            # the gradient pass left W = L^-1 in Ky and a = L^-1 y in dv["a"]: V = W k*, no refactorisation
+            Ks = rt.matrix(self.n, m)
+            rc = rt.lib.gpx_gpr_predict_inv(
+                rt.h, key[0], ptr(dv["X"]), self.n, dv["X"].shape[1], self.dim, key[1], beta_p, key[3],
+                ptr(dv["a"]), ptr(dv["Ky"]), dv["Ky"].shape[1], ptr(dXs), m, dXs.shape[1], ptr(Ks),
+                ptr(V), V.shape[1], ptr(mean), ptr(cov) if full_cov else None,
+                cov.shape[1] if full_cov else 0, None if full_cov else ptr(var), 1 if full_cov else 0)
+            _lib.check(rc, "gpx_gpr_predict_inv")
         mean_h = rt.download(mean[:m])
         if full_cov:
             return mean_h, rt.download(cov[:m, :m])

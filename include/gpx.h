@@ -167,6 +167,15 @@ int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, in
                     int ldv, double* vec, double* mean, double* cov, int ldc, double* var,
                     int full_cov);
 
+/* The same prediction (regression.py:31-44) when the gradient pass has already turned the factor into
+ * its inverse: W = L^-1 (lower, what gpx_gpr_lml_grad leaves in Ky) and a = L^-1 y (its a_out).
+ * V = L^-1 k* is then the triangular MULTIPLY W k* -- no second factorisation after an optimiser
+ * evaluation, and one GEMM instead of a solve.  Ks: n x ldv scratch for k* (distinct from V). */
+int gpx_gpr_predict_inv(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
+                        const double* beta_host, double noise, const double* a, const double* W, int ldw,
+                        const double* Xs, int m, int ldxs, double* Ks, double* V, int ldv, double* mean,
+                        double* cov, int ldc, double* var, int full_cov);
+
 /* ---- EP inner linear algebra (expectation_propagation.py:61-65, 90-94) ------------------ */
 /* B = I + (s s^T) o K  (lower) and SK = diag(s) K (full), s = sqrt(tau). */
 int gpx_ep_scale(gpx_handle* h, int n, const double* K, int ldk, const double* s, double* B,

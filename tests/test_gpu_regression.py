@@ -51,9 +51,15 @@ def test_fixed_theta_matches_reference(name):
     for k, ref in (("sigma", g["grad_sigma"]), ("cov__sigma", g["grad_cov_sigma"]),
                    ("cov__beta", g["grad_cov_beta"])):
         assert np.abs(grads[k] - ref).max() <= 1e-8 * scale, k
-    # LML again after the gradient pass (cached) and prediction after it (re-factorisation)
+    # LML again after the gradient pass (cached) and prediction after it: the gradient pass turned the
+    # factor into its inverse, so V = L^-1 k* is a triangular multiply (gpx_gpr_predict_inv), no refactorisation
     assert gp.log_marginal_likelihood() == lml
+    assert gp._state["has_factor"] is False
     assert relerr(gp.predict(g["Xs"]), g["mean"]) < TOL
+    mean3, cov3 = gp.predict_with_variance(g["Xs"])
+    assert gp._state["has_factor"] is False and gp._state["grad"] is not None      # still the gradient's state
+    assert relerr(mean3, g["mean"]) < TOL and relerr(cov3, g["pcov"]) < TOL
+    assert relerr(gp.predict_with_variance(g["Xs"], full_cov=False)[1], np.diagonal(g["pcov"])) < 1e-8
 
 
 def test_regression_1d_notebook_flow():

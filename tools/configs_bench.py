@@ -60,7 +60,7 @@ def c3(n=16384, m=4096):
         mean, cov = gp.predict_with_variance(Xs)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-    print("C3 n=%d m=%d: fused LML+grad %.3f s (%.1f TFLOP/s on n^3 flops), predict (full cov, incl. refactor + download) %.3f s, LML %.4f"
+    print("C3 n=%d m=%d: fused LML+grad %.3f s (%.1f TFLOP/s on n^3 flops), predict after the gradient (full cov, from the inverse factor, incl. download) %.3f s, LML %.4f"
           % (n, m, t1 - t0, n ** 3 / (t1 - t0) / 1e12, t2 - t1, lml), flush=True)
 
 
