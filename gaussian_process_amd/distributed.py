@@ -153,7 +153,7 @@ class DistributedGP:
         # owner of the next panel starts on a piece as soon as it has arrived and sends its own piece
         # on at once, so the factorisation chain carries one piece per step, not a whole panel.
         if row_chunk is None:
-            row_chunk = max(block, 4096 if world >= 8 else 8192 if world >= 4 else 16384)
+            row_chunk = max(block, 8192 if world >= 4 else 16384)
         assert row_chunk % block == 0, "row_chunk must be a multiple of block"
         self.row_chunk = row_chunk
         # Column width of the gradient's own partition.  Wide slabs cut the number of launches (every
