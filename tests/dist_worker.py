@@ -122,8 +122,21 @@ def run(world, case):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=worker, args=(r, world, port, case, q)) for r in range(world)]
-    for p in procs:
-        p.start()
+    # CPU ranks (NumPy test double): one BLAS thread each, or `world` ranks x all cores oversubscribe the host.
+    # Spawned children read the variables when they import numpy; the parent's value is restored below.
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    if not case.get("gpu"):
+        for k in saved:
+            os.environ[k] = "1"
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     import queue
     import time
     outs, deadline = [], time.monotonic() + 150

@@ -38,6 +38,20 @@ def test_world3_matches_oracle():
         assert o["L"] < 1e-12 and o["lml"] < 1e-11 and o["mean"] < 1e-10 and o["cov"] < 1e-9, o
 
 
+@pytest.mark.parametrize("world,case", [
+    (4, dict(n=1700, m=10, d=3, block=128, kind="ard", update_k=256, row_chunk=256, grad_block=128)),   # 14 blocks on 4 ranks
+    (8, dict(n=2200, m=12, d=2, block=128, kind="ard", update_k=256, row_chunk=512, grad_block=128)),   # 18 blocks on 8 ranks
+], ids=["world4", "world8"])
+def test_more_ranks_match_oracle(world, case):
+    """The ownership / look-ahead / deferral pattern of the 4- and 8-rank runs (owner of k+2 is another
+    rank than the owners of k and k+1; some ranks own 2 columns, some 3)."""
+    outs = _run(world, case)
+    assert len(outs) == world
+    for o in outs:
+        assert o["L"] < 1e-12 and o["lml"] < 1e-11 and o["alpha"] < 1e-9 and o["grad"] < 1e-9, o
+        assert o["mean"] < 1e-10 and o["cov"] < 1e-9 and o["res"] < 1e-10, o
+
+
 def test_world2_not_positive_definite_reported_on_every_rank():
     # duplicated-point Gram with negative "noise": first failing minor is rank-independent
     outs = _run(2, dict(n=400, m=4, d=2, block=128, kind="ard", noise=-0.5, expect_fail=True))
