@@ -36,6 +36,16 @@ def test_world3_gpu_matches_oracle():
         assert o["L"] < 1e-12 and o["lml"] < 1e-11 and o["mean"] < 1e-9 and o["cov"] < 1e-9, o
 
 
+def test_world4_gpu_matches_oracle():
+    """Four ranks sharing the GPU (gloo): the 4-rank ownership / deferral pattern on the real kernels."""
+    outs = _run(4, dict(n=4000, m=40, d=8, block=256, kind="ard", gpu=True, update_k=512, row_chunk=1024,
+                        grad_block=256))
+    assert len(outs) == 4
+    for o in outs:
+        assert o["L"] < 1e-12 and o["lml"] < 1e-11 and o["alpha"] < 1e-9 and o["grad"] < 1e-9, o
+        assert o["mean"] < 1e-9 and o["cov"] < 1e-9 and o["res"] < 1e-10, o
+
+
 def test_world2_gpu_not_positive_definite():
     outs = _run(2, dict(n=700, m=4, d=2, block=128, kind="ard", noise=-0.5, expect_fail=True, gpu=True))
     assert outs[0]["info"] > 0 and outs[0]["info"] == outs[1]["info"]
