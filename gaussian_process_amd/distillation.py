@@ -49,7 +49,7 @@ class GaussianProcessDistillation(GaussianProcessExpectationPropagation):
         self.fit(self.Xtr, self.ytr, self.str)
 
     def posterior(self, X):
-        Ks_ = self.cov(self.Xtr, X).K
+        Ks_ = self._cross_cov(X)
         Kss = self.cov(X, diag=True).K
         return self._posterior(np.vstack([Ks_, self.rho * Ks_]), Kss)
 

@@ -185,8 +185,14 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
             self._L_host = np.tril(dv["rt"].download(dv["B"][: dv["n"], : dv["n"]]))
         return self._L_host
 
+    def _cross_cov(self, X):
+        """K(Xtr, X) on the host; without the derivative planes when the kernel can skip them."""
+        if hasattr(self.cov, "gram_only"):
+            return self.cov.gram_only(self.Xtr, X)
+        return self.cov(self.Xtr, X).K
+
     def posterior(self, X):
-        Ks = self.cov(self.Xtr, X).K
+        Ks = self._cross_cov(X)
         Kss = self.cov(X, diag=True).K
         return self._posterior(Ks, Kss)
 

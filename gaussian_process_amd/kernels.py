@@ -69,6 +69,14 @@ class _StationaryKernel(BaseEstimator):
         return (rt.download(K[:n1, :n2]), rt.download(dsig[:n1, :n2]),
                 rt.download(dbeta[:, :n1, :n2]))
 
+    def gram_only(self, X1, X2=None):
+        """K(X1, X2) as a host array without the derivative planes ``__call__`` also builds and downloads
+        (kernels.py:38-39, 80-81): what posterior()/predict() need."""
+        X1 = _as_2d(X1, "X1")
+        X2 = X1 if X2 is None else _as_2d(X2, "X2")
+        assert X1.shape[1] == X2.shape[1], "X1 and X2 must have the same number of features"
+        return self._evaluate(X1, X2, want_dtheta=False)[0]
+
     def device_gram(self, X, diag_add=0.0):
         """K(X, X) + diag_add * I as a device-resident matrix (full, symmetric): what the estimators use
         when the host copy that ``__call__`` returns is not needed.  Same argument checks as
