@@ -25,6 +25,9 @@ import time
 
 import numpy as np
 
+# multi-process GPU work on this pool needs dmabuf IPC (the image exports it; keep it if a launcher dropped it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
