@@ -429,17 +429,22 @@ class DistributedGP:
         nbeta = len(self.beta)
         total = np.zeros(2 + nbeta)
         # The gradient has its own column partition (every rank holds all of L, so any partition
-        # works): wide blocks for GEMM efficiency, dealt in snake order (r, 2P-1-r, 2P+r, ...) because
-        # the cost of a block falls like (n - j0)^2 and plain cyclic dealing would load rank 0 twice
-        # as heavily as the last rank.
+        # works): wide slabs for GEMM efficiency.  The cost of a slab falls like (n - j0)^2, so plain
+        # cyclic dealing would load rank 0 twice as heavily as the last rank; slabs are handed out
+        # heaviest first to the least loaded rank instead (same deterministic list on every rank:
+        # max/mean load 1.00 / 1.01 / 1.02 on 2 / 4 / 8 ranks at n = 65536, against 1.01 / 1.08 / 1.10
+        # for dealing them in snake order r, 2P-1-r, ...).
         gb = min(self.grad_block, ((n + 127) // 128) * 128)
         if getattr(self, "slab", None) is None or self.slab.numel() < n * gb:
             self.slab = ops.empty(n * gb)
         nblk = (n + gb - 1) // gb
-        for k in range(nblk):
-            pos = k % (2 * self.world)
-            if (pos if pos < self.world else 2 * self.world - 1 - pos) != self.rank:
-                continue
+        loads, mine = [0] * self.world, []
+        for k in range(nblk):            # k ascending = cost descending
+            r = loads.index(min(loads))
+            loads[r] += (n - k * gb) ** 2 * min(gb, n - k * gb)
+            if r == self.rank:
+                mine.append(k)
+        for k in mine:
             k0, kb = k * gb, min(gb, n - k * gb)
             nk, lds = n - k0, kb + (kb & 1)
             S = self.slab[: nk * lds].view(nk, lds)
