@@ -552,11 +552,14 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   static const bool log_shapes = getenv("GPX_GEMM_LOG") != nullptr;   // development: one line per launch
   if (log_shapes)
     fprintf(stderr, "GEMMLOG %d %d %d lower=%d atri=%d btri=%d inplace=%d cfg=%d\n", g.M, g.N, g.K, g.c_lower,
-            g.a_tri, g.b_tri, g.inplace, (g.inplace == GPX_INPLACE_A && g.M <= 16384) ? 1 : (g.inplace || big_tiles >= 384) ? 4 : 2);
+            g.a_tri, g.b_tri, g.inplace, (g.inplace == GPX_INPLACE_A && g.M <= 16384) ? 1 : (g.inplace == GPX_INPLACE_B && g.N <= 16384) ? 41 : (g.inplace || big_tiles >= 384) ? 4 : 2);
   // In-place right-multiplies (D aliases A, N <= 128) with few rows: 32-row tiles, still 128 wide, so
   // that a 128 x 128 x 128 leaf solve is spread over 4 CUs instead of being one CU's 13.7 us of MFMA
   // time.  (When D aliases B the workgroup must own all K = M <= 128 rows: 128-row tiles only.)
   if (g.inplace == GPX_INPLACE_A && g.M <= 16384) return launch_cfg<1, 4>(s, g);
+  // The mirror image for in-place left-multiplies (D aliases B, M = K <= 128: the leaves of the left
+  // solves): 128 x 32 tiles, the workgroup still owns all 128 rows of its column panel.
+  if (g.inplace == GPX_INPLACE_B && g.N <= 16384) return launch_cfg<4, 1>(s, g);
   if (g.inplace || big_tiles >= 384) return launch_cfg<4, 4>(s, g);
   return launch_cfg<2, 2>(s, g);
 }
