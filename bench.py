@@ -35,7 +35,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD spec; 256 CU x 4 S
 # Fabric-side traffic of ONE dominant launch (M=N=K=16384), from rocprofv3 PMC passes of tools/gemm_launch.py
 # (profiles/r01_gemm_launch_pmc_*.csv): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB -> bytes.  The counter
 # sits on the L2's memory side, so Infinity-Cache hits are included: it is an upper bound on HBM bytes.
-GEMM_LAUNCH_TRAFFIC_BYTES = int((2 * 106.6e6 + 2.097152e6) * 1024)
+GEMM_LAUNCH_TRAFFIC_BYTES = int((2 * 109.1e6 + 2.097152e6) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
