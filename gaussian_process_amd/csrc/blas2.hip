@@ -141,6 +141,34 @@ __global__ __launch_bounds__(256) void ep_scale_kernel(int n, const double* K, l
 
 }  // namespace
 
+// ---- the allocation-free variant's scratch (gpx_gemv_static) ------------------------------------
+// Partials of the transposed GEMV live in this file-scope device array instead of the handle's
+// hipMalloc'ed scratch.  Every GPU the library is loaded on holds its own copy (2 MiB) at its own
+// address until the process ends; host code never uses the array's name as an address -- the per-device
+// address comes from hipGetSymbolAddress at gpx_create and is what the kernels receive.
+static __device__ __align__(256) double scratch[GPX_STATIC_SCRATCH_ELEMS];
+static double* g_scratch_ptr[GPX_MAX_DEVICES] = {nullptr};
+
+int gpx_static_scratch_init(int device) {
+  if (device < 0 || device >= GPX_MAX_DEVICES) {
+    gpx_set_error("static scratch: device %d outside [0, %d)", device, GPX_MAX_DEVICES);
+    return GPX_EINVAL;
+  }
+  if (g_scratch_ptr[device] != nullptr) return 0;
+  double* p = nullptr;   // the caller has made `device` current
+  GPX_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
+  if (p == nullptr) {
+    gpx_set_error("static scratch: hipGetSymbolAddress returned a null address on device %d", device);
+    return GPX_EHIP;
+  }
+  g_scratch_ptr[device] = p;
+  return 0;
+}
+
+double* gpx_static_scratch(int device) {
+  return (device >= 0 && device < GPX_MAX_DEVICES) ? g_scratch_ptr[device] : nullptr;
+}
+
 // rows per partial-sum chunk: GV_ROWS, doubled while chunks x m would overflow the scratch
 static int chunk_rows(int n, int m, size_t red_elems) {
   int rows = GV_ROWS;

@@ -255,6 +255,8 @@ int gpx_create(gpx_handle** out, int device) {
   GPX_HIP(hipGetDeviceProperties(&prop, device));
   GPX_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
               "gpx_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+  // this GPU's address of the file-scope scratch of gpx_gemv_static (no allocation: a symbol lookup)
+  GPX_TRY(gpx_static_scratch_init(device));
   gpx_handle* h = new gpx_handle();
   h->device = device;
   if (hipMalloc(&h->red, GPX_RED_ELEMS * sizeof(double)) != hipSuccess ||
@@ -454,6 +456,21 @@ int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, c
   GPX_REQUIRE(lda >= m, "gemv: lda too small");
   DeviceGuard dg(h->device);
   return gpx_gemv_launch(h->stream, trans, n, m, A, lda, x, y, h->red, RED_USABLE);
+}
+
+int gpx_gemv_static(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,
+                    double* y) {
+  GPX_REQUIRE(h != nullptr && A && x && y, "gemv_static: null argument");
+  GPX_REQUIRE(n >= 0 && m >= 0 && lda >= m, "gemv_static: bad shape (n %d, m %d, lda %d)", n, m, lda);
+  GPX_REQUIRE((size_t)m <= GPX_STATIC_SCRATCH_ELEMS && n <= (1 << 28),
+              "gemv_static: %d x %d exceeds the static scratch (m <= %zu, n <= 2^28); use gpx_gemv", n, m,
+              GPX_STATIC_SCRATCH_ELEMS);
+  double* sc = gpx_static_scratch(h->device);
+  GPX_REQUIRE(sc != nullptr, "gemv_static: static scratch of device %d was not initialised", h->device);
+  DeviceGuard dg(h->device);
+  // the partial kernel overwrites every slot the final kernel reads, so the previous call's contents
+  // of the shared array need no clearing
+  return gpx_gemv_launch(h->stream, trans, n, m, A, lda, x, y, sc, GPX_STATIC_SCRATCH_ELEMS);
 }
 
 int gpx_symmetrize(gpx_handle* h, int n, double* A, int lda) {

@@ -19,6 +19,8 @@ struct gpx_handle {
 
 constexpr size_t GPX_RED_ELEMS = 1u << 23;  // 64 MiB of reduction partials
 constexpr size_t GPX_HOST_PIN = 4096;
+constexpr size_t GPX_STATIC_SCRATCH_ELEMS = 1u << 18;  // 2 MiB file-scope device array (gpx_gemv_static)
+constexpr int GPX_MAX_DEVICES = 64;
 constexpr int GPX_MAXD = 32;  // max input dimension held in kernel-argument betas
 
 void gpx_set_error(const char* fmt, ...);
@@ -93,6 +95,8 @@ int gpx_ep_sweep_launch(hipStream_t s, int n, double* Sigma, long ld, const doub
                         const int* order_host, int count, double* work);
 
 // blas2.hip
+int gpx_static_scratch_init(int device);   // once per device, that device current (called by gpx_create)
+double* gpx_static_scratch(int device);    // device address of this GPU's copy of the static scratch
 int gpx_logdet_launch(hipStream_t s, int n, const double* L, long ldl, double* red, double* out_dev);
 int gpx_dot_launch(hipStream_t s, int n, const double* x, const double* y, double* red, double* out_dev);
 int gpx_gemv_launch(hipStream_t s, int trans, int n, int m, const double* A, long lda,

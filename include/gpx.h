@@ -122,6 +122,14 @@ int gpx_trmm(gpx_handle* h, int n, int m, const double* L, int ldl, const double
  * regression.py:39 (mean = a . V), expectation_propagation.py:65,94,116. */
 int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,
              double* y);
+/* gpx_gemv for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc): the same kernels, but the partial sums of the transposed product live in a
+ * file-scope 2 MiB device array of the library instead of the handle's hipMalloc'ed scratch.  It has no
+ * counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine.  Limits: m <= 262144
+ * (2^18) and n <= 2^28, larger shapes return GPX_EINVAL.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads) race; calls on one stream are ordered. */
+int gpx_gemv_static(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,
+                    double* y);
 /* out_host[0] = x . y */
 int gpx_dot(gpx_handle* h, int n, const double* x, const double* y, double* out_host);
 /* Mirror the lower triangle into the upper one (symmetric full matrix for NumPy consumers). */
