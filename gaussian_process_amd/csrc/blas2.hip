@@ -212,13 +212,13 @@ int gpx_colsumsq_sub_launch(hipStream_t s, int n, int m, const double* V, long l
                             double* var, double* red, size_t red_elems) {
   if (m <= 0) return 0;
   const int rows = chunk_rows(n, m, red_elems);
-  const int nchunks = (n + rows - 1) / rows;
+  const int nchunks = n <= 0 ? 0 : (n + rows - 1) / rows;
   if ((size_t)nchunks * m > red_elems) {
     gpx_set_error("colsumsq: reduction scratch too small (%d x %d)", n, m);
     return GPX_ENOMEM;
   }
   dim3 grid((m + 255) / 256, nchunks);
-  hipLaunchKernelGGL(colsumsq_partial_kernel, grid, dim3(256), 0, s, n, m, V, ldv, red, rows);
+  if (nchunks > 0) hipLaunchKernelGGL(colsumsq_partial_kernel, grid, dim3(256), 0, s, n, m, V, ldv, red, rows);
   hipLaunchKernelGGL(colsumsq_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nchunks, m, red,
                      base, var);
   GPX_HIP(hipGetLastError());

@@ -473,6 +473,13 @@ int gpx_gemv_static(gpx_handle* h, int trans, int n, int m, const double* A, int
   return gpx_gemv_launch(h->stream, trans, n, m, A, lda, x, y, sc, GPX_STATIC_SCRATCH_ELEMS);
 }
 
+int gpx_colsumsq_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double base, double* var) {
+  GPX_REQUIRE(h != nullptr && V && var, "colsumsq_sub: null argument");
+  GPX_REQUIRE(n >= 0 && m >= 0 && ldv >= m, "colsumsq_sub: bad shape (n %d, m %d, ldv %d)", n, m, ldv);
+  DeviceGuard dg(h->device);
+  return gpx_colsumsq_sub_launch(h->stream, n, m, V, ldv, base, var, h->red, RED_USABLE);
+}
+
 int gpx_symmetrize(gpx_handle* h, int n, double* A, int lda) {
   GPX_REQUIRE(h != nullptr && A, "symmetrize: null argument");
   DeviceGuard dg(h->device);
@@ -558,6 +565,11 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
   // L = chol(Ky), regression.py:49
   GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
   GPX_TRY(potrf_rec(s, n, Ky, ldk, dinv, h->info_dev, 0));
+  // not positive definite (an L-BFGS-B excursion): return at once, as scipy's cholesky raises at
+  // regression.py:49 -- no solves, no inverse, no traces on a garbage factor
+  int info = 0;
+  GPX_TRY(fetch_info(h, &info));
+  if (info != 0) return info;
   // a = L^-1 y (regression.py:50), alpha = L^-T a (= Ky^-1 y, regression.py:61).  vec: n x 2 rhs
   const long ldv = 2;
   double* rhs = vec;            // n x 2 (col 0 used)
@@ -590,9 +602,6 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
   }
   double host[GPX_MAXD + 8];
   GPX_TRY(fetch(h, sc, host, nfetch));
-  int info = 0;
-  GPX_TRY(fetch_info(h, &info));
-  if (info != 0) return info;
   *lml_host = -0.5 * host[0] - host[1] - 0.5 * n * log(2.0 * M_PI);
   if (grad_host) finish_grad(nbeta, sigma, b, host + 2, grad_host);
   return 0;

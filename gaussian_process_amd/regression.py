@@ -81,6 +81,9 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         if need_grad and dv["Kinv"] is None:
             dv["Kinv"] = rt.matrix(n, n)
         kind, sigma_k, beta = key[0], key[1], np.array(key[2])
+        # the call overwrites the resident factor: whatever was cached is gone from here on, also if
+        # the call raises (LinAlgError at a non-PD trial theta of L-BFGS-B)
+        self._state = None
         _, beta_p = _keep = _lib.host_doubles(beta)
         lml = C.c_double(0.0)
         ngrad = 2 + len(beta)

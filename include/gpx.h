@@ -122,6 +122,10 @@ int gpx_trmm(gpx_handle* h, int n, int m, const double* L, int ldl, const double
  * regression.py:39 (mean = a . V), expectation_propagation.py:65,94,116. */
 int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,
              double* y);
+/* var[j] = base - sum_i V[i][j]^2 for V n x m: the diagonal of K** - V^T V + noise I (regression.py:41-44)
+ * and of expectation_propagation.py:118 without the m x m matrix; fixed-order reduction.  The multi-GPU
+ * path sums the per-rank results (base = 0 on all ranks but one). */
+int gpx_colsumsq_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double base, double* var);
 /* gpx_gemv for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc): the same kernels, but the partial sums of the transposed product live in a
  * file-scope 2 MiB device array of the library instead of the handle's hipMalloc'ed scratch.  It has no

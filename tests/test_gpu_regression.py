@@ -205,3 +205,57 @@ def test_default_noise_stress_case_matches_oracle():
         assert np.abs(g[k] - g_o[k]).max() < 1e-9 * scale
     mean, cov = gp.predict_with_variance(Xs)
     assert relerr(mean, mean_o) < 1e-9 and relerr(cov, cov_o) < 1e-9
+
+
+def test_failed_evaluation_does_not_leave_a_stale_cache():
+    """A non-PD trial theta (an L-BFGS-B excursion) overwrites the resident factor and raises; going
+    back to the previous theta must re-evaluate, not serve the cache that described the destroyed
+    buffers (regression.py:46-55 recomputes every time, so the reference cannot get this wrong)."""
+    from gaussian_process_amd import ARD, GaussianProcessRegression
+    X, y, Xs, beta = O.synthetic_ard(500, m=40, d=3, seed=11)
+    gp = GaussianProcessRegression(ARD(sigma=1.1, beta=beta), sigma=0.05)
+    gp.fit(X, y)
+    lml0 = gp.log_marginal_likelihood()
+    gp.set_params(sigma=-5.0)                      # K - 5 I is indefinite
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.grad_log_marginal_likelihood()
+    assert gp._state is None
+    gp.set_params(sigma=0.05)
+    mean_o, cov_o = O.gpr_predict("ard", X, y, Xs, 1.1, beta, 0.05)
+    mean, cov = gp.predict_with_variance(Xs)
+    assert relerr(mean, mean_o) < TOL and relerr(cov, cov_o) < TOL
+    assert gp.log_marginal_likelihood() == lml0
+    assert relerr(gp.alpha_(), O.gpr_grad("ard", X, y, 1.1, beta, 0.05)[1]) < TOL
+
+
+def test_not_positive_definite_returns_before_the_inverse():
+    """gpx_gpr_lml_grad reads LAPACK info right after the factorisation: a non-PD theta costs a Gram +
+    a (failed) potrf, not the trtri + lauum + traces on a garbage factor (2/3 of the evaluation)."""
+    import time
+    import torch
+    from gaussian_process_amd import ARD, GaussianProcessRegression
+    n = 8192
+    X, y, _, beta = O.synthetic_ard(n, m=4, d=8, seed=4)
+    gp = GaussianProcessRegression(ARD(sigma=1.0, beta=beta), sigma=0.1)
+    gp.fit(X, y)
+    gp.grad_log_marginal_likelihood()              # warm: buffers allocated, kernels loaded
+
+    def timed(fn, sigma, fails):
+        gp.set_params(sigma=sigma)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if fails:
+            with pytest.raises(np.linalg.LinAlgError):
+                fn()
+        else:
+            fn()
+        return time.perf_counter() - t0
+
+    t_grad = min(timed(gp.grad_log_marginal_likelihood, 0.1 + 1e-7 * i, False) for i in (1, 2, 3))
+    t_lml = min(timed(gp.log_marginal_likelihood, 0.1 + 1e-7 * i, False) for i in (4, 5, 6))
+    # K - 0.5 I fails in an early leading minor, but the factorisation kernels run to the end either way
+    t_bad = min(timed(gp.grad_log_marginal_likelihood, -0.5 - 1e-3 * i, True) for i in (1, 2, 3))
+    # measured on MI355X at n = 8192: gradient evaluation 20 ms, LML-only (Gram + potrf + 2 solves) 9.9 ms,
+    # failed gradient evaluation 9.7 ms (19.4 ms before the early return)
+    assert t_bad < 1.1 * t_lml + 1e-3, (t_bad, t_lml, t_grad)
+    assert t_bad < 0.7 * t_grad, (t_bad, t_lml, t_grad)
