@@ -1,8 +1,8 @@
 """bench.py's N > 1 leg: one rank per GPU, RCCL, strong scaling at fixed n (BASELINE configs[3]).
 
-A step is the same fit+predict pass as at N = 1: Gram of the owned block
-columns, distributed potrf (distributed.py), replicated alpha / LML, predict split over the test
-columns, and the LML gradient from per-owner block columns of Ky^-1.
+A step is the same fit+predict pass as at N = 1 on the 2-D block-cyclic,
+sharded layout (distributed.py): Gram of the owned slabs, distributed potrf, alpha / LML and prediction
+by the fan-in triangular solves, and the LML gradient from slabs of Ky^-1.
 value = n^3/3 / (potrf time, max over ranks)."""
 import json
 import os
@@ -13,18 +13,20 @@ import numpy as np
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
 
-def main(args, rank, local_rank, world):
+def main(args, rank, local_rank, world, cpu_baseline=None, traffic=None):
     import torch
     import torch.distributed as dist
-    from . import _lib
     from .device import runtime
-    from .distributed import DistributedGP, GpuOps
+    from .distributed import DistributedGP, GpuOps, default_block
 
     backend = os.environ.get("GPX_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)          # several ranks on one GPU only in gloo rehearsals
     torch.cuda.set_device(dev_index)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
@@ -35,10 +37,13 @@ def main(args, rank, local_rank, world):
     from .datasets import synthetic_ard
     n, m, d = args.n, args.m, 8
     X, y, Xs, beta = synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
-    gp = DistributedGP(GpuOps(rt), dist, rank, world, block=getattr(args, "block", 0) or {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024),
-                       row_chunk=int(os.environ.get("GPX_ROW_CHUNK", "0")) or None,   # env: development overrides
-                       grad_block=int(os.environ.get("GPX_GRAD_BLOCK", "0")) or None,
-                       update_k=int(os.environ.get("GPX_UPDATE_K", "0")) or None)
+    grid = None
+    if os.environ.get("GPX_GRID"):                 # env: development override, "PxQ"
+        grid = tuple(int(v) for v in os.environ["GPX_GRID"].lower().split("x"))
+    gp = DistributedGP(GpuOps(rt), dist, rank, world, block=getattr(args, "block", 0) or default_block(world),
+                       grid=grid, grad_block=int(os.environ.get("GPX_GRAD_BLOCK", "0")) or None,
+                       update_k=int(os.environ.get("GPX_UPDATE_K", "0")) or None,
+                       force_collectives=world == 1)   # on one rank the collectives still run (groups of one)
     sigma, noise = 1.0, 0.1
 
     def step(marks):
@@ -82,12 +87,14 @@ def main(args, rank, local_rank, world):
         for (n0, e0), (n1, e1) in zip(mk[:-1], mk[1:]):
             stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / args.steps
     names = ["gram", "potrf", "solve_lml", "predict", "grad"]
-    vec = torch.tensor([wall] + [stages[k] for k in names], dtype=torch.float64, device=rt.dev)
+    mem = gp.resident_bytes
+    vec = torch.tensor([wall] + [stages[k] for k in names] + [float(mem["matrix"]), float(mem["panels"])],
+                       dtype=torch.float64, device=rt.dev)
     dist.all_reduce(vec, op=dist.ReduceOp.MAX)
     vec = vec.cpu().numpy()
     wall = float(vec[0])
-    stages = {k: float(v) for k, v in zip(names, vec[1:])}
-    # parity property at full size, on every rank's replica of alpha: || Ky alpha - y || / || y ||
+    stages = {k: float(v) for k, v in zip(names, vec[1:6])}
+    # parity property at full size: || Ky alpha - y || / || y || with Ky rebuilt by the Gram kernel
     res = gp.residual()
     if rank == 0:
         potrf_tflops = n ** 3 / 3 / (stages["potrf"] / 1e3) / 1e12
@@ -99,20 +106,28 @@ def main(args, rank, local_rank, world):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "synthetic ARD regression n=%d d=8 m=%d, noise 0.1 (BASELINE configs[3])" % (n, m),
-                       "parallelism": "block-column-cyclic x%d, block %d, panel broadcasts (%s) in pieces of %d rows, look-ahead 1"
-                                      % (world, gp.block, backend, gp.row_chunk),
-                       "step": "gram + potrf + alpha/LML + predict + LML gradient (block columns of Ky^-1 per owner)"},
+                       "parallelism": "2-D block-cyclic %dx%d grid, tile %d, sharded storage; diagonal tile down the "
+                                      "process column, panel along the process row, transposed all-gather in the "
+                                      "column (%s); look-ahead 1, updates delayed to K=%d"
+                                      % (gp.P, gp.Q, gp.nb, backend, gp.g_upd * gp.nb),
+                       "step": "gram + potrf + alpha/LML + predict + LML gradient (fan-in solves; Ky^-1 by slabs of %d columns)"
+                               % gp.grad_block},
             "fit_predict_wall_s": round(ms / 1e3, 4),
             "fit_predict_without_gradient_s": round(sum(stages[k] for k in names[:4]) / 1e3, 4),
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+            "resident_bytes_per_rank_max": {"matrix": int(vec[6]), "panels": int(vec[7]),
+                                            "lower_triangle_over_world": int(mem["lower_over_world"])},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (potrf phase, whole job)",
                          "achieved": round(potrf_tflops, 3), "peak": FP64_MFMA_PEAK_TFLOPS * world,
                          "unit": "TFLOP/s", "frac": round(potrf_tflops / (FP64_MFMA_PEAK_TFLOPS * world), 4),
-                         "traffic": None},
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None},
             "parity": {"lml": lml, "residual_Ky_alpha_minus_y_rel": res,
                        "mean_finite": bool(np.isfinite(mean.cpu().numpy()).all()),
                        "grad": [float(g) for g in grad]},
         }
+        if cpu_baseline is not None:
+            out["cpu_baseline"] = cpu_baseline()          # rank 0 only, after the timed region
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -1,38 +1,49 @@
-"""Multi-GPU exact GP regression: block-column-cyclic Cholesky with panel broadcasts over
+"""Multi-GPU exact GP regression: 2-D block-cyclic, SHARDED Cholesky and triangular solves over
 ``torch.distributed`` (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
 
 One process per GPU.  The reference has no distributed code at all; what is distributed here is
-the arithmetic of regression.py:31-55 (Gram, ``cholesky``, the triangular solves, LML, predictive
-mean / covariance), with the same kernels as the single-GPU path (libgpx) doing all local work.
+the arithmetic of regression.py:31-76 (Gram, ``cholesky``, the triangular solves, LML, its gradient,
+predictive mean / covariance), with the same kernels as the single-GPU path (libgpx) doing all
+local work.
 
-Layout and algorithm (realised 1-D for round 1):
-  * every rank holds an n x n row-major buffer; block column j (width ``block``, rows >= j*block)
-    is OWNED by rank j % P, which builds it (Gram, no communication: X is replicated) and applies
-    every trailing update to it;
-  * step k: the owner factors the diagonal block (``gpx_potrf_async``), solves the panel below it
-    (``gpx_trsm_right``), packs panel k (+ its 128x128 diagonal-block inverses) into a contiguous
-    staging buffer and broadcasts it in row pieces; every rank files the panel into its buffer, so
-    after the last step EVERY rank holds the complete factor L, and applies the filed panels to its
-    own block columns j > k a few at a time, ``A[j0:, j] -= A[j0:, c0:c1] A[j, c0:c1]^T`` (one MFMA
-    GEMM with a long K instead of one per panel);
-  * look-ahead: the owner of panel k+1 brings its column up to date with panel k piece by piece as
-    the pieces arrive, factors it and posts its own pieces (async, RCCL's own stream) before the bulk
-    updates of step k are enqueued, so the transfers and the panel factorisation hide under the
-    other ranks' GEMMs;
-  * solves after the factorisation are split by right-hand-side column: rank r computes
-    ``V[:, cols_r] = L^-1 k*(:, cols_r)``; V is all-gathered for the ``V^T V`` block rows.
-Communication per step: the broadcasts of one panel, (n - k*block) x block doubles in all (the whole
-lower triangle once per rank over the factorisation, 17 GB at n = 65536) -- no other data-path collective.
+Layout (index maps in grid2d.py): a P x Q process grid, rank = p * Q + q; the
+matrix is cut into nb x nb tiles and tile (I, J), I >= J, lives on process (I mod P, J mod Q).  A
+process keeps one contiguous slab per tile column it owns (its tiles of that column from the
+diagonal down): the resident matrix is the lower triangle / (P Q), nothing is replicated.
+
+Factorisation, step k (right-looking, look-ahead 1, delayed trailing updates):
+  1. the diagonal owner factors tile (k, k) (``gpx_potrf_async``) and broadcasts it with its
+     128 x 128 diagonal-block inverses down its process COLUMN (sub-communicator of P ranks);
+  2. the P processes of that column solve their rows of the panel (``gpx_trsm_right``);
+  3. each broadcasts its rows along its process ROW (sub-communicator of Q ranks): every process
+     then holds L[I, k] for its tile rows I -- the left operand of its trailing update;
+  4. transposed exchange: inside every process column the ranks all-gather the tiles L[J, k] with
+     J mod Q == q: the right operand (J runs over the process's tile COLUMNS);
+  5. local update A[I, J] -= L[I, k] L[J, k]^T.  The last G panels stay in two ring buffers (by local
+     row / local column), so a tile column absorbs several panels in ONE GEMM with a long K.
+Per step a process receives (1/P + 1/Q) of the panel, not all of it.
+
+After the factorisation L never moves.  ``L^-1 B`` runs right-looking with fan-in: the ranks of
+process column (k mod Q) subtract L[I, k] X[k] from the partial sums of their rows, the partial sums of
+row k are reduced along the process row to the diagonal owner, which solves X[k] and broadcasts it
+down its column.  ``L^-T B`` is the mirror image (reduce down the column, broadcast along the row).
+Only right-hand-side tiles travel: (n/P + n/Q) m doubles per solve and rank.  alpha / LML use m = 1,
+prediction m test points, the LML gradient slabs of identity columns (Ky^-1 by tile-row slabs, never
+whole) contracted on the fly by ``gpx_grad_trace_slab``; scalars are all-reduced.
 """
 import ctypes as C
+from contextlib import contextmanager
 
 import numpy as np
 
 from . import _lib
+from .grid2d import Grid2D, default_grid
 
 
-def owner_of(block_index, world):
-    return block_index % world
+def default_block(world):
+    """Tile size nb per world size: wide tiles keep the local GEMMs efficient, narrow ones shorten the
+    factorisation chain (its length is n / nb steps whatever the number of ranks)."""
+    return {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024)
 
 
 class _Done:
@@ -100,6 +111,11 @@ class GpuOps:
         _lib.check(self.lib.gpx_gemv(self.h, 0, A.shape[0], A.shape[1], self._p(A), A.stride(0), self._p(x),
                                      self._p(y)), "gpx_gemv")
 
+    def colsumsq(self, V, base, var):
+        """var[j] = base - sum_i V[i][j]^2."""
+        _lib.check(self.lib.gpx_colsumsq_sub(self.h, V.shape[0], V.shape[1], self._p(V), V.stride(0), float(base),
+                                             self._p(var)), "gpx_colsumsq_sub")
+
     def grad_trace_slab(self, kind, sigma, beta, X, d, alpha, slab, row_off, col_off):
         barr, bp = _lib.host_doubles(beta)
         out = (C.c_double * (2 + len(barr)))()
@@ -109,8 +125,8 @@ class GpuOps:
                                                 C.cast(out, C.POINTER(C.c_double))), "gpx_grad_trace_slab")
         return np.array(list(out))
 
-    # ---- a second stream for work that should overlap the main stream (the diagonal-block potrf of
-    # the look-ahead panel is a chain of one-workgroup kernels; the column update fills the other CUs)
+    # ---- a second stream for work that should overlap the main stream (the diagonal-tile potrf of
+    # the look-ahead column is a chain of one-workgroup kernels; the column update fills the other CUs)
     def side_begin(self):
         t = self.torch
         if not hasattr(self, "_side"):
@@ -132,99 +148,181 @@ class GpuOps:
     def side_join(self, ev):
         self.torch.cuda.current_stream(self.device).wait_event(ev)
 
+    @contextmanager
+    def forward_stream(self):
+        """Stream context for the copies and collectives that only FORWARD a received panel (the
+        transposed exchange): ordered after what the compute stream has enqueued so far, but not
+        behind what it enqueues next (the bulk trailing updates)."""
+        t = self.torch
+        if not hasattr(self, "_fwd"):
+            self._fwd = t.cuda.Stream(device=self.device)
+        ev = t.cuda.Event()
+        ev.record(t.cuda.current_stream(self.device))
+        self._fwd.wait_event(ev)
+        with t.cuda.stream(self._fwd):
+            yield
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
 
 class DistributedGP:
-    """Exact GP regression over the ranks of a torch.distributed process group."""
+    """Exact GP regression over the ranks of a torch.distributed process group, 2-D block-cyclic."""
 
-    def __init__(self, ops, dist, rank, world, block=2048, group=None, update_k=None, grad_block=None,
-                 row_chunk=None):
+    def __init__(self, ops, dist, rank, world, block=2048, grid=None, update_k=None, grad_block=None, group=None,
+                 force_collectives=False):
         assert block % _lib.GPX_NB == 0, "block must be a multiple of 128"
         self.ops, self.dist, self.rank, self.world, self.block, self.group = ops, dist, rank, world, block, group
         self.torch = ops.torch
-        # K the delayed trailing updates aim for (see potrf).  Longer K is cheaper per flop (world 1,
-        # block 512: potrf 1.77 s at K = 1024, 1.67 at 2048, 1.63 at 4096, 1.62 at 8192) but one such GEMM
-        # must stay short next to a factorisation step, because the next panel's chain queues behind
-        # it on the same stream: 8192 on one rank, 4096 on two, 2048 beyond.
+        self.P, self.Q = grid if grid is not None else default_grid(world)
+        assert self.P * self.Q == world, "grid %dx%d does not match world size %d" % (self.P, self.Q, world)
+        self.p, self.q = divmod(rank, self.Q)
+        # K the delayed trailing updates aim for: a tile column absorbs update_k / block panels in one
+        # GEMM (K = block alone runs 15-20 % slower on the MFMA kernel and rewrites the column every step)
         self.update_k = update_k or {1: 8192, 2: 4096}.get(world, 2048)
-        # Rows per piece of a panel broadcast (absolute row grid, a multiple of the block width): the
-        # owner of the next panel starts on a piece as soon as it has arrived and sends its own piece
-        # on at once, so the factorisation chain carries one piece per step, not a whole panel.
-        if row_chunk is None:
-            row_chunk = max(block, 8192 if world >= 4 else 16384)
-        assert row_chunk % block == 0, "row_chunk must be a multiple of block"
-        self.row_chunk = row_chunk
-        # Column width of the gradient's own partition.  Wide slabs cut the number of launches (every
-        # slab solve walks all 128-row leaves of L: measured at world 1, n = 65536: 4.78 s at 1024,
-        # 3.75 s at 2048, 3.33 s at 4096), narrow ones balance the ranks (max/mean load of the snake
-        # order at 8 ranks: 1.03 at 1024, 1.10 at 2048, 1.37 at 4096).
-        self.grad_block = grad_block or (4096 if world <= 4 else 2048)
-        self._gloo = dist.get_backend(group) == "gloo"
+        # columns of Ky^-1 per gradient slab (each slab is one forward + one backward solve)
+        self.grad_block = grad_block or 4096
+        # which communicators carry traffic: a dimension of extent 1 needs none.  force_collectives
+        # issues them anyway (groups of one rank): the world-size-1 rehearsal of the RCCL branch.
+        self.rc = self.Q > 1 or force_collectives          # row sub-communicator (Q ranks)
+        self.cc = self.P > 1 or force_collectives          # column sub-communicator (P ranks)
+        self.wc = world > 1 or force_collectives           # world group
+        self._gloo = self.wc and dist.get_backend(group) == "gloo"
+        self.row_group = self.col_group = None
+        # every rank creates every sub-communicator, in the same order
+        for p in range(self.P):
+            g = dist.new_group([p * self.Q + q for q in range(self.Q)]) if self.rc else None
+            if p == self.p:
+                self.row_group = g
+        for q in range(self.Q):
+            g = dist.new_group([p * self.Q + q for p in range(self.P)]) if self.cc else None
+            if q == self.q:
+                self.col_group = g
         self.n = 0
+        self._ws = {}
 
-    # ------------------------------------------------------------------ helpers
-    def _blocks(self):
-        b = self.block
-        return [(k, k * b, min(b, self.n - k * b)) for k in range((self.n + b - 1) // b)]
+    # ------------------------------------------------------------------ collectives
+    def _staged(self, t):
+        return t.is_cuda and self._gloo
 
-    def _dinv_slice(self, k0, kb):
-        nb = _lib.GPX_NB
-        lo = (k0 // nb) * nb * nb
-        return self.dinv[lo: lo + ((kb + nb - 1) // nb) * nb * nb]
-
-    def _bcast(self, t, src, async_op=False):
-        """Broadcast a contiguous device buffer.  RCCL: asynchronous on RCCL's stream, ordered after
-        the kernels already enqueued; wait() makes the compute stream wait, not the host.  gloo
-        (rehearsals with several ranks on one GPU, CPU tests): staged through the host and
-        completed before returning."""
-        if t.is_cuda and self._gloo:
-            host = t.cpu()                       # synchronises with the kernels that produced t
-            self.dist.broadcast(host, src=src, group=self.group)
+    def _bcast(self, t, src, group, async_op=False):
+        """Broadcast a contiguous buffer inside `group` (src = global rank).  RCCL: asynchronous on
+        RCCL's stream, ordered after the kernels already enqueued on the current stream; wait() makes
+        the current stream wait, not the host.  gloo with device tensors (rehearsals with several ranks
+        on one GPU): staged through the host and completed before returning."""
+        if self._staged(t):
+            host = t.cpu()
+            self.dist.broadcast(host, src=src, group=group)
             if self.rank != src:
                 t.copy_(host)
             return _Done()
-        w = self.dist.broadcast(t, src=src, group=self.group, async_op=async_op)
+        w = self.dist.broadcast(t, src=src, group=group, async_op=async_op)
         return w if async_op else _Done()
 
-    def _all_reduce(self, t, op):
-        if t.is_cuda and self._gloo:
+    def _reduce(self, t, dst, group):
+        """Sum `t` over `group` into rank dst's `t` (the other ranks' buffers are scratch afterwards)."""
+        if self._staged(t):
             host = t.cpu()
-            self.dist.all_reduce(host, op=op, group=self.group)
-            return host
-        self.dist.all_reduce(t, op=op, group=self.group)
+            self.dist.reduce(host, dst=dst, op=self.dist.ReduceOp.SUM, group=group)
+            if self.rank == dst:
+                t.copy_(host)
+            return
+        self.dist.reduce(t, dst=dst, op=self.dist.ReduceOp.SUM, group=group)
+
+    def _all_reduce(self, t, op=None, group=None):
+        op = op or self.dist.ReduceOp.SUM
+        if not self.wc:
+            return t
+        if self._staged(t):
+            host = t.cpu()
+            self.dist.all_reduce(host, op=op, group=group or self.group)
+            t.copy_(host)
+            return t
+        self.dist.all_reduce(t, op=op, group=group or self.group)
         return t
 
-    def _all_gather(self, outs, mine):
-        """all_gather; gloo has no device all_gather, so there it is P broadcasts (test rigs only)."""
-        if mine.is_cuda and self._gloo:
-            for s in range(self.world):
-                if s == self.rank:
-                    outs[s].copy_(mine)
-                self._bcast(outs[s], s)
+    def _all_gather(self, out, mine, group, async_op=False):
+        """out (members x len(mine)) <- every member's `mine`, in group-rank order."""
+        if self._staged(mine):
+            host = mine.cpu()
+            parts = [self.torch.empty_like(host) for _ in range(out.shape[0])]
+            self.dist.all_gather(parts, host, group=group)
+            out.copy_(self.torch.stack(parts))
+            return _Done()
+        if self._gloo or not mine.is_cuda:
+            self.dist.all_gather([out[i] for i in range(out.shape[0])], mine, group=group)
+            return _Done()
+        w = self.dist.all_gather_into_tensor(out.view(-1), mine, group=group, async_op=async_op)
+        return w if async_op else _Done()
+
+    @contextmanager
+    def _forwarding(self):
+        if self._gloo or not self.cc or not hasattr(self.ops, "forward_stream"):
+            yield
         else:
-            self.dist.all_gather(outs, mine, group=self.group)
+            with self.ops.forward_stream():
+                yield
+
+    def _grank(self, p, q):
+        return p * self.Q + q
 
     # ------------------------------------------------------------------ fit
     def allocate(self, X, y, kind, sigma, beta, noise):
-        """Upload the (replicated) inputs and allocate everything fit/predict keep resident."""
+        """Upload the (replicated, 8 n d bytes) inputs and allocate everything fit/predict keep
+        resident: this process's slabs of the matrix and the panel workspaces."""
         ops, t = self.ops, self.torch
         n, d = X.shape
         self.n, self.d = n, d
         self.set_theta(kind, sigma, beta, noise)
-        ld = max(32, ((n + 31) // 32) * 32)
-        self.A = ops.empty(n, ld)
-        self.X = ops.zeros(n, max(32, ((d + 31) // 32) * 32))
-        self.X[:, :d].copy_(t.from_numpy(np.ascontiguousarray(X, dtype=np.float64)))
+        nb = min(self.block, ((n + 127) // 128) * 128)
+        g = self.grid = Grid2D(n, nb, self.P, self.Q)
+        self.nb, self.T = nb, g.T
+        p, q = self.p, self.q
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        ldx = max(32, ((d + 31) // 32) * 32)
+        self.X = ops.zeros(n, ldx)
+        self.X[:, :d].copy_(t.from_numpy(X))
+        # the rows of X of this process row's tile rows, in local order (left operand of the Gram slabs)
+        nlr, nlc = g.nlr(p), g.nlc(q)
+        Xr = np.zeros((max(nlr, 1) * nb, d))
+        for I in g.local_rows(p):
+            Xr[g.lrow(I): g.lrow(I) + g.tile_h(I)] = X[I * nb: I * nb + g.tile_h(I)]
+        self.Xrow = ops.zeros(max(nlr, 1) * nb, ldx)
+        self.Xrow[:, :d].copy_(t.from_numpy(Xr))
         self.y = ops.empty(max(n, 2))
         self.y[:n].copy_(t.from_numpy(np.ascontiguousarray(y, dtype=np.float64)))
-        self.dinv = ops.empty(max(((n + 127) // 128) * 128 * 128, 2))
+        # ---- the resident matrix: one slab (whole tiles high, nb wide) per owned tile column
+        self.slab_rows = {J: g.slab_rows(p, J) for J in g.local_cols(q)}
+        self.slab_tiles = {J: len(g.local_rows(p, J)) for J in g.local_cols(q)}
+        total = sum(self.slab_tiles[J] * nb * nb for J in self.slab_tiles)
+        self.store = ops.empty(max(total, 2))
+        self.slabs, off = {}, 0
+        for J in g.local_cols(q):
+            cnt = self.slab_tiles[J] * nb * nb
+            self.slabs[J] = self.store[off: off + cnt].view(self.slab_tiles[J] * nb, nb)
+            off += cnt
+        dper = (nb // 128) * 128 * 128
+        diag = g.diag_tiles(p, q)
+        self.dinv_store = ops.empty(max(len(diag) * dper, 2))
+        self.dinv = {k: self.dinv_store[i * dper: i * dper + ((g.tile_h(k) + 127) // 128) * 128 * 128]
+                     for i, k in enumerate(diag)}
         self.info = ops.zeros(64, dtype=t.int32)
-        b = min(self.block, ((n + 127) // 128) * 128)
-        cap = n * b + ((b + 127) // 128) * 128 * 128
-        self.stg = [ops.empty(cap), ops.empty(cap)]     # double-buffered panel staging
-        self.rhs = ops.zeros(n, 2)
+        # ---- panel workspaces: ring buffers of the last G panels, by local row and by local column
+        self.g_upd = max(1, self.update_k // nb)
+        self.G = self.g_upd + 2
+        self.RB = ops.empty(max(nlr, 1) * nb, self.G * nb)
+        self.CB = ops.empty(max(nlc, 1) * nb, self.G * nb)
+        self.rowstg = [ops.empty(max(nlr, 1) * nb * nb) for _ in range(2)]
+        cmax = max([g.transposed_max(q, k) for k in range(g.T)] + [1])
+        self.tsend = ops.empty(cmax * nb * nb)
+        self.trecv = [ops.empty(self.P, cmax * nb * nb) for _ in range(2)]
+        self.dstg = [ops.empty(nb * nb + dper) for _ in range(2)]
+        self._ws = {}
+        self.resident_bytes = dict(matrix=8 * total,
+                                   panels=8 * (self.RB.numel() + self.CB.numel() + 2 * self.rowstg[0].numel()
+                                               + self.tsend.numel() + 2 * self.trecv[0].numel()
+                                               + 2 * self.dstg[0].numel()),
+                                   lower_over_world=8 * g.lower_elems() // self.world)
 
     def set_theta(self, kind, sigma, beta, noise):
         """Hyper-parameters of the next build_gram(): kernel kind ("rbf" / "ard" or the C ABI's id),
@@ -243,284 +341,412 @@ class DistributedGP:
 
     def fit(self, X, y, kind, sigma, beta, noise):
         """Gram + distributed Cholesky + alpha + LML.  X (n, d), y (n,) host arrays, identical on
-        every rank.  Returns the LML; the factor stays resident on every rank for predict()."""
+        every rank.  Returns the LML; the sharded factor stays resident for predict() / grad()."""
         self.allocate(X, y, kind, sigma, beta, noise)
         self.build_gram()
         self.potrf()
         return self.solve_lml()
 
     def build_gram(self):
-        """Each rank fills only the block columns it owns (rows from the diagonal block down)."""
-        for k, k0, kb in self._blocks():
-            if owner_of(k, self.world) != self.rank:
+        """Each process fills its own slabs from the replicated X (kernels.py:77-79 + the noise of
+        regression.py:48 on the diagonal tiles): no communication."""
+        g, d, nb = self.grid, self.d, self.nb
+        for J, slab in self.slabs.items():
+            rows = self.slab_rows[J]
+            if rows == 0:
                 continue
-            Xv = self.X[:, : self.d]
-            self.ops.gram(self.kind, self.sigma, self.beta, Xv[k0:], Xv[k0:k0 + kb],
-                          self.A[k0:self.n, k0:k0 + kb], self.noise)
+            I0 = g.first_at_or_after(J, self.p, self.P)
+            wJ = g.tile_h(J)
+            self.ops.gram(self.kind, self.sigma, self.beta, self.Xrow[g.lrow(I0): g.lrow(I0) + rows, :d],
+                          self.X[J * nb: J * nb + wJ, :d], slab[:rows, :wJ], self.noise if I0 == J else 0.0)
 
-    def _row_chunks(self, k0):
-        """Row ranges [r0, r1) of panel k (rows k0..n) on the absolute row_chunk grid."""
-        n, rc = self.n, self.row_chunk
-        cuts = [k0] + list(range((k0 // rc + 1) * rc, n, rc)) + [n]
-        return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
-
-    def _panel_len(self, k0, kb):
-        return (self.n - k0) * kb + self._dinv_slice(k0, kb).numel()
-
-    def _send_panel(self, k, k0, kb, owner, produce=None):
-        """Broadcast panel k (in stg[k % 2]) piece by piece, the diagonal-block inverses last; every
-        rank issues the same sequence of collectives.  On the owner `produce(r0, r1)` computes and
-        packs the rows [r0, r1) right before they are sent.  Returns [(last row + 1, handle), ...]."""
-        stg = self.stg[k % 2]
-        nk = self.n - k0
-        handles = []
-        for r0, r1 in self._row_chunks(k0):
-            if produce is not None:
-                produce(r0, r1)
-            handles.append((r1, self._bcast(stg[(r0 - k0) * kb:(r1 - k0) * kb], owner, async_op=True)))
-        dlen = self._dinv_slice(k0, kb).numel()
-        handles.append((None, self._bcast(stg[nk * kb: nk * kb + dlen], owner, async_op=True)))
-        return handles
-
-    def _producer(self, k, k0, kb, prev=None):
-        """Owner side of panel k as a per-piece callback for _send_panel.  prev = (Pprev, kprev0,
-        handles of panel k-1) or None for the first panel.  First piece: (look-ahead: bring the
-        diagonal block up to date with panel k-1,) potrf of the diagonal block -- on the side stream
-        while the main stream updates the rows below it --, then per piece: update with panel k-1,
-        TRSM against the diagonal block, pack.  A piece only waits for the piece of panel k-1 that
-        holds the same rows."""
-        n, ops = self.n, self.ops
-        stg = self.stg[k % 2]
-        Akk = self.A[k0:k0 + kb, k0:k0 + kb]
-        dk = self._dinv_slice(k0, kb)
-        state = {"arrived": 0}
-
-        def wait_rows(r1):
-            """Make the main stream wait for the pieces of panel k-1 up to the one holding row r1 - 1."""
-            if prev is None:
-                return
-            hs, i = prev[2], state["arrived"]
-            while i < len(hs) and hs[i][0] is not None and (i == 0 or hs[i - 1][0] < r1):
-                hs[i][1].wait()
-                i += 1
-            state["arrived"] = i
-
-        def produce(r0, r1):
-            wait_rows(r1)
-            first = r0 == k0
-            lo = k0 + kb if first else r0
-            token = None
-            if prev is not None:
-                Pp, kp0 = prev[0], prev[1]
-                top = Pp[k0 - kp0: k0 - kp0 + kb]
-                if first:
-                    ops.gemm(0, 1, kb, kb, Pp.shape[1], -1.0, top, top, 1.0, Akk)
-                    ops.side_begin()
-                    ops.potrf_async(Akk, dk, self.info, k0)
-                    token = ops.side_end()
-                if r1 > lo:
-                    ops.gemm(0, 1, r1 - lo, kb, Pp.shape[1], -1.0, Pp[lo - kp0: r1 - kp0], top, 1.0,
-                             self.A[lo:r1, k0:k0 + kb])
-                if token is not None:
-                    ops.side_join(token)
-            elif first:
-                ops.potrf_async(Akk, dk, self.info, k0)
-            if r1 > lo:
-                ops.trsm_right(self.A[lo:r1, k0:k0 + kb], Akk, dk)
-            stg[(r0 - k0) * kb:(r1 - k0) * kb].view(r1 - r0, kb).copy_(self.A[r0:r1, k0:k0 + kb])
-            if first:
-                nk = n - k0
-                stg[nk * kb: nk * kb + dk.numel()].copy_(dk)
-
-        return produce
-
-    def _apply_filed(self, j0, jb, c0, c1):
-        """A[j0:, J] -= A[j0:, c0:c1] A[J, c0:c1]^T: the panels filed in columns [c0, c1) applied to
-        block column J = [j0, j0+jb) in ONE GEMM with K = c1 - c0."""
-        if c1 <= c0:
+    # ------------------------------------------------------------------ factorisation
+    def _update(self, J, s0, cnt, r0, r1):
+        """slab_J[r0:r1] -= RB[rows, slots] CB[tile column J, slots]^T: `cnt` consecutive ring slots
+        starting at s0 applied to rows [r0, r1) of tile column J in ONE GEMM with K = cnt * nb."""
+        if r1 <= r0 or cnt <= 0:
             return
-        n = self.n
-        self.ops.gemm(0, 1, n - j0, jb, c1 - c0, -1.0, self.A[j0:n, c0:c1], self.A[j0:j0 + jb, c0:c1], 1.0,
-                      self.A[j0:n, j0:j0 + jb])
+        g, nb = self.grid, self.nb
+        base = g.lrow(g.first_at_or_after(J, self.p, self.P))
+        wJ = g.tile_h(J)
+        self.ops.gemm(0, 1, r1 - r0, wJ, cnt * nb, -1.0, self.RB[base + r0: base + r1, s0 * nb:(s0 + cnt) * nb],
+                      self.CB[g.lcol(J): g.lcol(J) + wJ, s0 * nb:(s0 + cnt) * nb], 1.0, self.slabs[J][r0:r1, :wJ])
+
+    def _apply(self, J, upto, r0=0, r1=None, commit=True):
+        """Apply the filed panels [applied[J], upto) to rows [r0, r1) of tile column J."""
+        a, G = self._applied[J], self.G
+        r1 = self.slab_rows[J] if r1 is None else r1
+        while a < upto:
+            s0 = a % G
+            cnt = min(upto - a, G - s0)
+            self._update(J, s0, cnt, r0, r1)
+            a += cnt
+        if commit:
+            self._applied[J] = upto
+
+    def _post_panel(self, k):
+        """Everything that produces panel k and starts it on its way: (column owners) bring tile
+        column k up to date, (diagonal owner) factor the diagonal tile and broadcast it down the
+        column, (column owners) solve their rows, then -- every process -- the row broadcast and the
+        transposed exchange.  Returns the handles _file_panel(k) waits for."""
+        g, ops, nb, P, Q, p, q = self.grid, self.ops, self.nb, self.P, self.Q, self.p, self.q
+        pk, qk = k % P, k % Q
+        has_panel = k < g.T - 1
+        wk = g.tile_h(k)
+        below = None
+        if q == qk:
+            slab, rows = self.slabs[k], self.slab_rows[k]
+            mine = p == pk
+            if mine:
+                # diagonal tile first; its potrf runs on the side stream while the rows below are updated
+                self._apply(k, k, 0, wk, commit=False)
+                ops.side_begin()
+                ops.potrf_async(slab[:wk, :wk], self.dinv[k], self.info, k * nb)
+                token = ops.side_end()
+                self._apply(k, k, wk, rows)
+                ops.side_join(token)
+            else:
+                self._apply(k, k)
+            if has_panel:
+                Lkk, dk = (slab[:nb], self.dinv[k]) if mine else (None, None)
+                if self.cc:
+                    dst = self.dstg[k % 2]
+                    if mine:
+                        dst[: nb * nb].view(nb, nb).copy_(slab[:nb])
+                        dst[nb * nb:].copy_(self.dinv[k])
+                    self._bcast(dst, self._grank(pk, qk), self.col_group, async_op=True).wait()
+                    if not mine:
+                        Lkk, dk = dst[: nb * nb].view(nb, nb), dst[nb * nb:]
+                below = slab[nb:rows] if mine else slab[:rows]
+                if below.shape[0] > 0:
+                    ops.trsm_right(below, Lkk, dk)
+        if not has_panel:
+            return None
+        # Row broadcast: skipped by a whole process row that has no tile rows below k.  The transposed
+        # exchange is joined by every rank of a process column that needs any tile, also by ranks whose
+        # own row piece is empty.
+        R = g.rows_from(p, k + 1)
+        ntiles = len(g.local_rows(p, k + 1))
+        piece, h_row = None, _Done()
+        if R > 0:
+            if q == qk:
+                start = nb if p == pk else 0
+                piece = self.slabs[k][start: start + ntiles * nb]          # whole tiles (slabs are padded)
+            else:
+                piece = self.rowstg[k % 2][: ntiles * nb * nb].view(ntiles * nb, nb)
+            if self.rc:
+                h_row = self._bcast(piece.reshape(-1)[: R * nb], self._grank(p, qk), self.row_group, async_op=True)
+        out = dict(R=R, piece=piece, h_row=h_row, cnt_max=g.transposed_max(q, k), h_T=_Done())
+        if out["cnt_max"] > 0 and self.cc:
+            t0, step, cnt = g.transposed_pick(p, q, k)
+            cm = out["cnt_max"]
+            with self._forwarding():
+                h_row.wait()
+                if cnt > 0:
+                    self.tsend[: cnt * nb * nb].view(cnt, nb, nb).copy_(piece.view(ntiles, nb, nb)[t0::step][:cnt])
+                out["h_T"] = self._all_gather(self.trecv[k % 2][:, : cm * nb * nb], self.tsend[: cm * nb * nb],
+                                              self.col_group, async_op=True)
+        return out
+
+    def _file_panel(self, k, h):
+        """Wait for panel k and file it into ring slot k % G: rows by local row, the transposed tiles by
+        local column."""
+        g, nb, P, Q, p, q = self.grid, self.nb, self.P, self.Q, self.p, self.q
+        if h is None:
+            return
+        slot = k % self.G
+        cols = slice(slot * nb, (slot + 1) * nb)
+        R = h["R"]
+        if R > 0:
+            I1 = g.first_at_or_after(k + 1, p, P)
+            h["h_row"].wait()
+            self.RB[g.lrow(I1): g.lrow(I1) + R, cols].copy_(h["piece"][:R])
+        if h["cnt_max"] == 0:
+            return
+        h["h_T"].wait()
+        nlc = self.CB.shape[0] // nb
+        CBt = self.CB.view(nlc, nb, self.G * nb)
+        stride = g.L // Q
+        for src in range(P):
+            t0, step, cnt = g.transposed_pick(src, q, k)
+            if cnt == 0:
+                continue
+            first = g.local_rows(src, k + 1)[t0]                       # a tile index I with I mod Q == q
+            if self.cc:
+                tiles = self.trecv[k % 2][src, : cnt * nb * nb].view(cnt, nb, nb)
+            else:
+                tiles = h["piece"].view(-1, nb, nb)[t0::step][:cnt]
+            CBt[first // Q:: stride][:cnt, :, cols].copy_(tiles)
 
     def potrf(self):
-        """Distributed right-looking Cholesky with DELAYED trailing updates and a row-pipelined
-        panel chain.  Every rank files every panel into its own buffer, so the panels a block column
-        still has to absorb sit side by side in A and are applied together: one GEMM with
-        K = (number of pending panels) x block instead of one short-K GEMM per panel (K = block is
-        15-20 % slower on the MFMA kernel and rewrites the column every step).  A column is forced up
-        to date one step before it becomes the look-ahead column, so the critical chain only ever
-        applies the newest panel -- and it does so piece by piece (row_chunk rows): the owner of panel
-        k+1 updates, solves and sends on the rows of a piece as soon as that piece of panel k is in,
-        so a panel's broadcast overlaps the next panel's factorisation instead of preceding it."""
-        ops, t, n, b = self.ops, self.torch, self.n, self.block
-        blocks = self._blocks()
+        """Distributed right-looking Cholesky (regression.py:36,49) with look-ahead 1 and delayed
+        trailing updates.  Returns LAPACK info (0, or the order of the first leading minor that is not
+        positive definite), the same value on every rank."""
+        g, t, T, G = self.grid, self.torch, self.T, self.G
         self.info.zero_()
-        group = max(1, self.update_k // b)                # panels per delayed update
-        applied = {j: 0 for j, _, _ in blocks}            # first panel column NOT yet applied to column j
-        k, k0, kb = blocks[0]
-        o0 = owner_of(0, self.world)
-        handles = self._send_panel(0, k0, kb, o0, self._producer(0, k0, kb) if o0 == self.rank else None)
-        for k, k0, kb in blocks:
-            cur = self.stg[k % 2]
-            nk = n - k0
-            Pk = cur[: nk * kb].view(nk, kb)
-            mine = owner_of(k, self.world) == self.rank
-            nxt = None
-            if k + 1 < len(blocks):
-                k1, k10, k1b = blocks[k + 1]
-                o1 = owner_of(k1, self.world)
-                produce = None
-                if o1 == self.rank:  # look-ahead: bring panel k+1 up to date, factor it, send it
-                    self._apply_filed(k10, k1b, applied[k1], k0)      # older panels (normally none)
-                    produce = self._producer(k1, k10, k1b, (Pk, k0, handles))
-                    applied[k1] = k0 + kb
-                nxt = self._send_panel(k1, k10, k1b, o1, produce)
-            for _, h in handles:
-                h.wait()
-            if not mine:  # file panel k (and its diagonal inverses) so every rank ends with all of L
-                self.A[k0:n, k0:k0 + kb].copy_(Pk)
-                dk = self._dinv_slice(k0, kb)
-                dk.copy_(cur[nk * kb: nk * kb + dk.numel()])
-            # The rank that factors panel k+2 next step enqueues only that column's catch-up now: its
-            # other updates would sit in the stream ahead of the chain it is about to run, and lose
-            # nothing by waiting one step (they come back with a longer K).
-            chain_next = k + 2 < len(blocks) and owner_of(k + 2, self.world) == self.rank
-            for j, j0, jb in blocks[k + 2:]:
-                if owner_of(j, self.world) != self.rank:
-                    continue
-                pending = (k0 + kb - applied[j] + b - 1) // b
-                if j == k + 2 or (pending >= group and not chain_next):
-                    self._apply_filed(j0, jb, applied[j], k0 + kb)
-                    applied[j] = k0 + kb
-            handles = nxt
+        self._applied = {J: 0 for J in self.slabs}
+        handles = self._post_panel(0)
+        for k in range(T - 1):
+            self._file_panel(k, handles)
+            # look-ahead: tile column k+1 is brought up to date, factored and sent before the bulk
+            handles = self._post_panel(k + 1)
+            # The process column that factors panel k+2 next step enqueues only that column's catch-up
+            # now: its other updates would sit in the stream ahead of the chain it is about to run, and
+            # lose nothing by waiting one step (they come back with a longer K).
+            chain_next = k + 2 < T and (k + 2) % self.Q == self.q
+            for J in g.local_cols(self.q, k + 2):
+                pending = k + 1 - self._applied[J]
+                if J == k + 2 or pending >= G - 1 or (pending >= self.g_upd and not chain_next):
+                    self._apply(J, k + 1)
         # LAPACK info: smallest failing leading minor over all ranks (0 = success)
         big = 2 ** 30
         loc = int(self.info[0].item())
-        val = t.tensor([loc if loc > 0 else big], dtype=t.int64, device=self.A.device)
+        val = t.tensor([loc if loc > 0 else big], dtype=t.int64, device=self.store.device)
         val = self._all_reduce(val, self.dist.ReduceOp.MIN)
         self.info_value = 0 if int(val.item()) >= big else int(val.item())
         return self.info_value
 
+    # ------------------------------------------------------------------ triangular solves
+    def _buffer(self, name, rows, cols):
+        buf = self._ws.get(name)
+        if buf is None or buf.shape[0] < rows or buf.shape[1] != cols:
+            buf = self._ws[name] = self.ops.empty(max(rows, 1), cols)
+        return buf
+
+    def rhs_buffer(self, m, zero=True):
+        """Right-hand-side / solution container of the solves: (local tile rows * nb) x ld, ld = m
+        rounded up to even.  Tile row k of B lives in rows [lrow(k), lrow(k) + h_k) of the DIAGONAL
+        OWNER of k; the other rows are the fan-in workspace (partial sums / received solution tiles)."""
+        ld = max(2, m + (m & 1))
+        R = self._buffer("rhs%d" % ld, self.grid.nlr(self.p) * self.nb, ld)
+        if zero:
+            R.zero_()
+        return R
+
+    def _solve_tile(self, trans, k, Rk, m):
+        hk = self.grid.tile_h(k)
+        self.ops.trsm_left(trans, self.slabs[k][:hk, :hk], self.dinv[k], Rk[:, :1] if m == 1 else Rk)
+
+    def solve_forward(self, R, m, t0=0):
+        """R <- L^-1 R (regression.py:37-38,50) on tile rows >= t0 (the right-hand side must be zero above
+        t0).  Right-looking, fan-in: after X[k] is known the ranks of process column k mod Q subtract
+        L[I, k] X[k] from the partial sums of their rows; the partial sums of row k are reduced along
+        process row k mod P onto the diagonal owner, which solves and broadcasts X[k] down its column."""
+        g, ops, nb, P, Q, p, q = self.grid, self.ops, self.nb, self.P, self.Q, self.p, self.q
+        ld = R.shape[1]
+        xb = self._buffer("xb%d" % ld, nb, ld)
+        for k in range(t0, g.T):
+            pk, qk, hk = k % P, k % Q, g.tile_h(k)
+            Rk = R[g.lrow(k): g.lrow(k) + hk]
+            if p == pk:
+                if self.rc:
+                    self._reduce(Rk, self._grank(pk, qk), self.row_group)
+                if q == qk:
+                    self._solve_tile(0, k, Rk, m)
+            if q == qk and k < g.T - 1:
+                Xk = Rk if p == pk else xb[:hk]
+                if self.cc:
+                    self._bcast(Xk, self._grank(pk, qk), self.col_group)
+                rows = g.rows_from(p, k + 1)
+                if rows > 0:
+                    I1 = g.first_at_or_after(k + 1, p, P)
+                    start = nb if p == pk else 0
+                    ops.gemm(0, 0, rows, ld, hk, -1.0, self.slabs[k][start: start + rows, :hk], Xk, 1.0,
+                             R[g.lrow(I1): g.lrow(I1) + rows])
+
+    def solve_backward(self, R, m, t0=0):
+        """R <- L^-T R (the second half of cho_solve behind regression.py:61) on tile rows >= t0.
+        Left-looking, fan-in, the mirror image of solve_forward: the ranks of process column k mod Q
+        form L[I>k, k]^T X[I>k] from the solution tiles resident in their rows, the partial results are
+        reduced down the column onto the diagonal owner, which solves X[k] and broadcasts it along its
+        process row (every rank of the row keeps it for the steps below)."""
+        g, ops, nb, P, Q, p, q = self.grid, self.ops, self.nb, self.P, self.Q, self.p, self.q
+        ld = R.shape[1]
+        part = self._buffer("part%d" % ld, nb, ld)
+        for k in range(g.T - 1, t0 - 1, -1):
+            pk, qk, hk = k % P, k % Q, g.tile_h(k)
+            Rk = R[g.lrow(k): g.lrow(k) + hk]
+            if q == qk:
+                rows = g.rows_from(p, k + 1)
+                mine = p == pk
+                tgt = Rk if mine else part[:hk]
+                if rows > 0:
+                    I1 = g.first_at_or_after(k + 1, p, P)
+                    start = nb if mine else 0
+                    ops.gemm(1, 0, hk, ld, rows, -1.0, self.slabs[k][start: start + rows, :hk],
+                             R[g.lrow(I1): g.lrow(I1) + rows], 1.0 if mine else 0.0, tgt)
+                elif not mine:
+                    tgt.zero_()
+                if self.cc:
+                    self._reduce(tgt, self._grank(pk, qk), self.col_group)
+                if mine:
+                    self._solve_tile(1, k, Rk, m)
+            if p == pk and self.rc:
+                self._bcast(Rk, self._grank(pk, qk), self.row_group)
+
+    def _own_tiles(self, t0=0):
+        return self.grid.diag_tiles(self.p, self.q, t0)
+
+    def _gather_vector(self, R):
+        """Column 0 of the solution container -> the full n-vector on every rank (all-reduce of n doubles)."""
+        g, nb = self.grid, self.nb
+        v = self.ops.zeros(max(self.n, 2))
+        for k in self._own_tiles():
+            hk = g.tile_h(k)
+            v[k * nb: k * nb + hk].copy_(R[g.lrow(k): g.lrow(k) + hk, 0])
+        return self._all_reduce(v)
+
     def solve_lml(self):
-        """a = L^-1 y, alpha = L^-T a, LML (regression.py:50-55, 61); replicated on every rank."""
-        ops, t, n = self.ops, self.torch, self.n
+        """a = L^-1 y, alpha = L^-T a, LML (regression.py:50-55, 61); every rank ends with the full a and
+        alpha (n doubles each) and the same LML."""
+        g, ops, t, n, nb = self.grid, self.ops, self.torch, self.n, self.nb
         _lib.check(self.info_value, "distributed potrf")
-        L = self.A[:n, :n]
-        rhs = self.rhs
-        rhs[:, 0].copy_(self.y[:n])
-        ops.trsm_left(0, L, self.dinv, rhs[:, :1])
-        self.a = rhs[:, 0].clone()
-        ops.trsm_left(1, L, self.dinv, rhs[:, :1])
-        self.alpha = rhs[:, 0].clone()
+        R = self.rhs_buffer(1)
+        for k in self._own_tiles():
+            hk = g.tile_h(k)
+            R[g.lrow(k): g.lrow(k) + hk, 0].copy_(self.y[k * nb: k * nb + hk])
+        self.solve_forward(R, 1)
+        self.a = self._gather_vector(R)
+        logdet = 0.0
+        for k in self._own_tiles():
+            hk = g.tile_h(k)
+            logdet += ops.logdet(self.slabs[k][:hk, :hk])
+        self.solve_backward(R, 1)
+        self.alpha = self._gather_vector(R)
         aa = ops.dot(n, self.a, self.a)
-        self.lml = -0.5 * aa - ops.logdet(L) - 0.5 * n * np.log(2.0 * np.pi)
+        ld_all = self._all_reduce(t.tensor([logdet], dtype=t.float64, device=self.store.device))
+        self.lml = -0.5 * aa - float(ld_all.item()) - 0.5 * n * np.log(2.0 * np.pi)
         return self.lml
 
     # ------------------------------------------------------------------ gradient
     def grad(self):
-        """regression.py:57-76 without ever forming Ky^-1 whole and without communication: every rank
-        holds all of L, so the owner of block column J computes the part of Ky^-1 on and below the
-        diagonal of J from the trailing sub-factor alone,
-            Kinv[j0:, J] = L[j0:, j0:]^-T ( L[j0:, j0:]^-1 [I; 0] )      ((n - j0)^2 b flops each, 2n^3/3 in all),
-        and adds its share of the trace sums (gpx_grad_trace_slab).  One all-reduce of d + 2 doubles.
+        """regression.py:57-76 on the sharded factor: Ky^-1 is formed by slabs of `grad_block` columns,
+        Kinv[c0:, slab] = L^-T (L^-1 [0; I; 0]) (one forward and one backward distributed solve on the
+        tile rows >= the slab's first; 2 n^3 / 3 flops in all, as trtri + lauum), and every diagonal owner
+        contracts the tile rows it ends up with against dK/dtheta on the fly (gpx_grad_trace_slab) --
+        Ky^-1 never exists whole.  One all-reduce of d + 2 doubles.
         Returns [d/d noise, d/d cov sigma, d/d cov beta...] (the reference's key order)."""
-        ops, t, n = self.ops, self.torch, self.n
+        g, ops, t, n, nb = self.grid, self.ops, self.torch, self.n, self.nb
         nbeta = len(self.beta)
         total = np.zeros(2 + nbeta)
-        # The gradient has its own column partition (every rank holds all of L, so any partition
-        # works): wide slabs for GEMM efficiency.  The cost of a slab falls like (n - j0)^2, so plain
-        # cyclic dealing would load rank 0 twice as heavily as the last rank; slabs are handed out
-        # heaviest first to the least loaded rank instead (same deterministic list on every rank:
-        # max/mean load 1.00 / 1.01 / 1.02 on 2 / 4 / 8 ranks at n = 65536, against 1.01 / 1.08 / 1.10
-        # for dealing them in snake order r, 2P-1-r, ...).
-        gb = min(self.grad_block, ((n + 127) // 128) * 128)
-        if getattr(self, "slab", None) is None or self.slab.numel() < n * gb:
-            self.slab = ops.empty(n * gb)
-        nblk = (n + gb - 1) // gb
-        loads, mine = [0] * self.world, []
-        for k in range(nblk):            # k ascending = cost descending
-            r = loads.index(min(loads))
-            loads[r] += (n - k * gb) ** 2 * min(gb, n - k * gb)
-            if r == self.rank:
-                mine.append(k)
-        for k in mine:
-            k0, kb = k * gb, min(gb, n - k * gb)
-            nk, lds = n - k0, kb + (kb & 1)
-            S = self.slab[: nk * lds].view(nk, lds)
-            S.zero_()
-            S[:kb, :kb].diagonal().fill_(1.0)
-            S = S[:, :kb]
-            Lsub = self.A[k0:n, k0:n]
-            dsub = self.dinv[(k0 // _lib.GPX_NB) * _lib.GPX_NB * _lib.GPX_NB:]
-            ops.trsm_left(0, Lsub, dsub, S)
-            ops.trsm_left(1, Lsub, dsub, S)
-            total += ops.grad_trace_slab(self.kind, self.sigma, self.beta, self.X, self.d, self.alpha, S, k0, k0)
-        tot = t.from_numpy(total).to(self.A.device)
-        tot = self._all_reduce(tot, self.dist.ReduceOp.SUM)
+        tiles_per_slab = max(1, self.grad_block // nb)
+        for t0 in range(0, g.T, tiles_per_slab):
+            t1 = min(g.T, t0 + tiles_per_slab)
+            w = sum(g.tile_h(J) for J in range(t0, t1))
+            R = self.rhs_buffer(w)
+            for k in self._own_tiles(t0):
+                if k < t1:
+                    hk = g.tile_h(k)
+                    R[g.lrow(k): g.lrow(k) + hk, (k - t0) * nb: (k - t0) * nb + hk].diagonal().fill_(1.0)
+            self.solve_forward(R, w, t0)
+            self.solve_backward(R, w, t0)
+            for k in self._own_tiles(t0):
+                hk = g.tile_h(k)
+                total += ops.grad_trace_slab(self.kind, self.sigma, self.beta, self.X, self.d, self.alpha,
+                                             R[g.lrow(k): g.lrow(k) + hk, :w], k * nb, t0 * nb)
+        tot = t.from_numpy(total).to(self.store.device)
+        tot = self._all_reduce(tot)
         return tot.cpu().numpy()
 
     # ------------------------------------------------------------------ predict
-    def predict(self, Xs):
-        """regression.py:31-44 with the m test points split over the ranks.  Returns (mean, cov) as
-        host arrays on every rank."""
-        mean, cov = self.predict_device(self.upload_test(Xs))
-        return mean.cpu().numpy(), cov.cpu().numpy()
+    def predict(self, Xs, full_cov=True):
+        """regression.py:31-44.  Returns (mean, cov) -- or (mean, diagonal variance) with
+        full_cov=False, which never forms the m x m matrix -- as host arrays on every rank."""
+        mean, second = self.predict_device(self.upload_test(Xs), full_cov=full_cov)
+        return mean.cpu().numpy(), second.cpu().numpy()
 
-    def predict_device(self, Xs_d):
-        ops, t, n, d, P, r = self.ops, self.torch, self.n, self.d, self.world, self.rank
+    def predict_device(self, Xs_d, full_cov=True):
+        """V = L^-1 k* by the distributed forward solve (the tile rows of V end on the diagonal owners),
+        mean = V^T a and cov = K** - V^T V + noise I (or its diagonal) from each owner's rows, all-reduced."""
+        g, ops, t, n, d, nb = self.grid, self.ops, self.torch, self.n, self.d, self.nb
         m = Xs_d.shape[0]
-        mc = (m + P - 1) // P
-        mc = max(2, mc + (mc & 1))                      # even chunk width (16-byte rows)
-        c0, c1 = min(m, r * mc), min(m, (r + 1) * mc)
-        L = self.A[:n, :n]
-        V = ops.zeros(n, mc)
-        if c1 > c0:
-            ops.gram(self.kind, self.sigma, self.beta, self.X[:, :d], Xs_d[c0:c1, :d], V[:, : c1 - c0], 0.0)
-            ops.trsm_left(0, L, self.dinv, V[:, : c1 - c0])
-        mean_loc = ops.zeros(mc)
-        ops.gemv_t(V, self.a, mean_loc)
-        means = [ops.empty(mc) for _ in range(P)]
-        self._all_gather(means, mean_loc)
-        mean = t.cat([means[s][: max(0, min(m, (s + 1) * mc) - min(m, s * mc))] for s in range(P)])
-        Vs = [ops.empty(n, mc) for _ in range(P)]
-        self._all_gather(Vs, V)
-        mpad = P * mc
-        cov_loc = ops.zeros(mc, mpad + (mpad & 1))
-        if c1 > c0:
-            for s in range(P):
-                s0, s1 = min(m, s * mc), min(m, (s + 1) * mc)
-                if s1 <= s0:
-                    continue
-                blk = cov_loc[: c1 - c0, s * mc: s * mc + (s1 - s0)]
-                ops.gram(self.kind, self.sigma, self.beta, Xs_d[c0:c1, :d], Xs_d[s0:s1, :d], blk,
-                         self.noise if s == r else 0.0)
-                ops.gemm(1, 0, c1 - c0, s1 - s0, n, -1.0, V, Vs[s], 1.0, blk)
-        covs = [ops.empty(mc, cov_loc.shape[1]) for _ in range(P)]
-        self._all_gather(covs, cov_loc)
-        rows = []
-        for s in range(P):
-            s0, s1 = min(m, s * mc), min(m, (s + 1) * mc)
-            if s1 > s0:
-                rows.append(t.cat([covs[s][: s1 - s0, q * mc: q * mc + max(0, min(m, (q + 1) * mc) - min(m, q * mc))]
-                                   for q in range(P)], dim=1))
-        return mean, t.cat(rows, dim=0)
+        R = self.rhs_buffer(m)
+        ld = R.shape[1]
+        own = self._own_tiles()
+        for k in own:
+            hk = g.tile_h(k)
+            ops.gram(self.kind, self.sigma, self.beta, self.X[k * nb: k * nb + hk, :d], Xs_d[:, :d],
+                     R[g.lrow(k): g.lrow(k) + hk, :m], 0.0)
+        self.solve_forward(R, m)
+        # this process's rows of V and of a, compacted (plumbing copies; the diagonal owners' tile rows
+        # are every (L/P)-th local tile row)
+        rows = max(len(own) * nb, 2)
+        Vc = self._buffer("Vc%d" % ld, rows, ld)
+        ac = self._buffer("ac", rows, 1).view(-1)
+        Vc.zero_()
+        ac.zero_()
+        for i, k in enumerate(own):
+            hk = g.tile_h(k)
+            Vc[i * nb: i * nb + hk].copy_(R[g.lrow(k): g.lrow(k) + hk])
+            ac[i * nb: i * nb + hk].copy_(self.a[k * nb: k * nb + hk])
+        Vc = Vc[:rows]
+        mean = ops.zeros(max(m, 2))
+        ops.gemv_t(Vc[:, :m], ac, mean)
+        mean = self._all_reduce(mean)[:m]
+        if not full_cov:
+            var = ops.zeros(max(m, 2))
+            ops.colsumsq(Vc[:, :m], (self.sigma + self.noise) if self.rank == 0 else 0.0, var)
+            return mean, self._all_reduce(var)[:m]
+        ldc = max(32, ((m + 31) // 32) * 32)
+        cov = ops.zeros(m, ldc)
+        if self.rank == 0:
+            ops.gram(self.kind, self.sigma, self.beta, Xs_d[:, :d], Xs_d[:, :d], cov[:, :m], self.noise)
+        ops.gemm(1, 0, m, m, rows, -1.0, Vc, Vc, 1.0, cov)
+        return mean, self._all_reduce(cov)[:, :m]
 
-    # ------------------------------------------------------------------ checks
-    def residual(self):
-        """|| Ky alpha - y || / || y || with Ky rebuilt row slab by row slab (a size-independent
-        parity property for the full-size runs; overwrites the factor)."""
-        ops, t, n, d, P, r = self.ops, self.torch, self.n, self.d, self.world, self.rank
-        rows = ((n + P - 1) // P + 1) // 2 * 2
-        r0, r1 = min(n, r * rows), min(n, (r + 1) * rows)
-        part = t.zeros(2, dtype=t.float64, device=self.A.device)
-        if r1 > r0:
-            slab = self.A[r0:r1, :n]
+    # ------------------------------------------------------------------ checks / diagnostics
+    def gather_lower(self):
+        """The whole lower-triangular matrix / factor on every rank as an n x n host array (strict
+        upper part zero).  Diagnostics and tests only: it undoes the sharding."""
+        g, nb, n = self.grid, self.nb, self.n
+        full = self.torch.zeros(n, n, dtype=self.torch.float64)
+        for J, slab in self.slabs.items():
+            wJ = g.tile_h(J)
+            host = slab.cpu()
+            for i, I in enumerate(g.local_rows(self.p, J)):
+                hI = g.tile_h(I)
+                blk = host[i * nb: i * nb + hI, :wJ]
+                full[I * nb: I * nb + hI, J * nb: J * nb + wJ] = blk.tril() if I == J else blk
+        return self._all_reduce_host(full).numpy()
+
+    def gather_dinv(self):
+        """All 128 x 128 diagonal-block inverses (ceil(n/128) x 128 x 128) on every rank; tests only."""
+        g, nb, n = self.grid, self.nb, self.n
+        nblk = (n + 127) // 128
+        full = self.torch.zeros(nblk, 128, 128, dtype=self.torch.float64)
+        for k, dk in self.dinv.items():
+            cnt = dk.numel() // (128 * 128)
+            full[k * (nb // 128): k * (nb // 128) + cnt] = dk.cpu().view(cnt, 128, 128)
+        return self._all_reduce_host(full).numpy()
+
+    def _all_reduce_host(self, full):
+        if self.world == 1:
+            return full
+        if self._gloo:
+            self.dist.all_reduce(full, group=self.group)
+            return full
+        dev = full.to(self.store.device)
+        self.dist.all_reduce(dev, group=self.group)
+        return dev.cpu()
+
+    def residual(self, chunk=2048):
+        """|| Ky alpha - y || / || y || with Ky rebuilt row chunk by row chunk into a scratch buffer, the
+        chunks dealt round-robin to the ranks (a size-independent parity property for the full-size
+        runs; the factor is not touched)."""
+        ops, t, n, d = self.ops, self.torch, self.n, self.d
+        ldn = max(32, ((n + 31) // 32) * 32)
+        scratch = self._buffer("resid", min(chunk, n), ldn)
+        out = ops.zeros(max(min(chunk, n), 2))
+        part = t.zeros(2, dtype=t.float64, device=self.store.device)
+        for i, r0 in enumerate(range(0, n, chunk)):
+            if i % self.world != self.rank:
+                continue
+            r1 = min(n, r0 + chunk)
+            slab = scratch[: r1 - r0, :n]
             ops.gram(self.kind, self.sigma, self.beta, self.X[r0:r1, :d], self.X[:, :d], slab, 0.0)
-            out = ops.zeros(max(r1 - r0, 2))
             ops.gemv_n(slab, self.alpha, out)
             res = out[: r1 - r0] + self.noise * self.alpha[r0:r1] - self.y[r0:r1]
-            part[0] = (res * res).sum()
-            part[1] = (self.y[r0:r1] ** 2).sum()
-        part = self._all_reduce(part, self.dist.ReduceOp.SUM)
+            part[0] += (res * res).sum()
+            part[1] += (self.y[r0:r1] ** 2).sum()
+        part = self._all_reduce(part)
         return float((part[0] / part[1]).sqrt().item())

@@ -10,12 +10,12 @@ computed redundantly from identical inputs, the gradient is all-reduced -- so L-
 """
 import numpy as np
 
-from .distributed import DistributedGP, GpuOps
+from .distributed import DistributedGP, GpuOps, default_block
 from .regression import GaussianProcessRegression
 
 
 class DistributedGaussianProcessRegression(GaussianProcessRegression):
-    #: (block, update_k, grad_block) of DistributedGP; None = its defaults for the world size
+    #: keyword options of DistributedGP (block, grid, update_k, grad_block); None = its defaults for the world size
     dist_options = None
     #: callable returning the per-rank primitive set; tests substitute a NumPy double
     ops_factory = None
@@ -36,7 +36,7 @@ class DistributedGaussianProcessRegression(GaussianProcessRegression):
                 rt.bind_stream()
                 ops = GpuOps(rt)
             opts = dict(self.dist_options or {})
-            opts.setdefault("block", {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024))
+            opts.setdefault("block", default_block(world))
             gp = self._gp = DistributedGP(ops, dist, rank, world, **opts)
         return gp
 
@@ -59,6 +59,7 @@ class DistributedGaussianProcessRegression(GaussianProcessRegression):
             gp.allocate(self.Xtr, self.ytr, key[0], key[1], np.array(key[2]), key[3])
             self._uploaded = True
         if st is None or st["key"] != key:
+            st = self._state = None      # the resident factor is overwritten from here on, also if potrf raises
             gp.set_theta(key[0], key[1], np.array(key[2]), key[3])
             gp.build_gram()
             gp.potrf()
@@ -73,11 +74,14 @@ class DistributedGaussianProcessRegression(GaussianProcessRegression):
         a = self._gp.alpha
         return a.detach().cpu().numpy()[: self.n].copy()
 
-    def predict_with_variance(self, X, full_cov=True, batch=None):
+    def predict_with_variance(self, X, full_cov=True, batch=16384):
+        """(mean, cov) as regression.py:31-44; ``full_cov=False`` returns the diagonal variance, never
+        forms the m x m matrix and streams the test points ``batch`` at a time, as the single-GPU
+        estimator does."""
         X = np.ascontiguousarray(np.asarray(X), dtype=np.float64)
         assert X.ndim == 2 and X.shape[1] == self.dim
         self._evaluate(need_grad=False)
-        mean, cov = self._gp.predict(X)
         if full_cov:
-            return mean, cov
-        return mean, np.ascontiguousarray(np.diagonal(cov))
+            return self._gp.predict(X)
+        parts = [self._gp.predict(X[i:i + batch], full_cov=False) for i in range(0, max(X.shape[0], 1), batch)]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])

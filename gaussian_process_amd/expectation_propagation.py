@@ -71,6 +71,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
     def _solve_vec(self, dv, rhs, trans):
         """L^-1 rhs (trans=0) or L^-T rhs (trans=1) for a host vector, on the GPU."""
         rt = dv["rt"]
+        rt.bind_stream()
         n = dv["n"]
         buf = rt.torch.zeros((n, 2), dtype=rt.torch.float64, device=rt.dev)
         buf[:, 0].copy_(rt.torch.from_numpy(np.ascontiguousarray(rhs, dtype=np.float64)))
@@ -81,6 +82,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
     def _solve_mat(self, dv, rhs):
         """L^-1 rhs for a host matrix (n x m)."""
         rt = dv["rt"]
+        rt.bind_stream()
         n = dv["n"]
         m = rhs.shape[1]
         buf = rt.upload_matrix(rhs)
@@ -215,6 +217,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         nu_cav = self.mu / dS - self.nu_tilde
         dv = self._dv
         rt = dv["rt"]
+        rt.bind_stream()
         ld = C.c_double(0.0)
         _lib.check(rt.lib.gpx_logdet(rt.h, dv["n"], ptr(dv["B"]), dv["B"].shape[1], C.byref(ld)),
                    "gpx_logdet")
@@ -232,21 +235,71 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         return terms if splitted_terms else sum(terms)
 
     def grad_log_marginal_likelihood(self, splitted_terms=False):
-        kernel = self.cov(self.Xtr)
-        K_grads = {"cov__" + k: v for k, v in kernel.dtheta.items()}
-        return {k: v if splitted_terms else np.sum(v)
-                for k, v in self._grad_log_marginal_likelihood(kernel.K, K_grads).items()}
-
-    def _grad_log_marginal_likelihood(self, K, K_grads):
-        """expectation_propagation.py:161-167: U = L^-1 diag(S) by TRSM, U^T U by the MFMA GEMM."""
+        """expectation_propagation.py:152-167.  For the stationary kernels of this package everything stays
+        on the device: U = L^-1 diag(S) (TRSM), U^T U (MFMA GEMM), b = nu - U^T U K nu (two GEMVs) and
+        the two trace terms per hyper-parameter by the fused trace kernel of the regression gradient
+        (gpx_grad_trace recomputes dK/dtheta from X: no n x n derivative planes, no n x n download,
+        no host matrix product).  The reference returns the PAIR [b^T dK b / 2, tr(U^T U dK) / 2] and,
+        without splitted_terms, their sum (as written at :158,166); kept."""
+        if not hasattr(self.cov, "gram_params"):
+            kernel = self.cov(self.Xtr)
+            K_grads = {"cov__" + k: v for k, v in kernel.dtheta.items()}
+            return {k: v if splitted_terms else np.sum(v)
+                    for k, v in self._grad_log_marginal_likelihood(kernel.K, K_grads).items()}
         dv = self._dv
-        rt = dv["rt"]
-        n = dv["n"]          # size of K: self.n here, 2 self.n under distillation.py
-        U = self._solve_mat(dv, np.diag(self.S.ravel()))
+        rt, n = dv["rt"], dv["n"]
+        rt.bind_stream()
+        lib, torch = rt.lib, rt.torch
+        UtU = self._UtU_device(dv)
+        # b = nu - U^T U (K + eps I) nu  (K resident since the fit, jitter included: :163-164)
+        nu_d = rt.upload_vector(self.nu_tilde)
+        t1, t2 = rt.vector(n), rt.vector(n)
+        _lib.check(lib.gpx_gemv(rt.h, 0, n, n, ptr(dv["K"]), dv["K"].shape[1], ptr(nu_d), ptr(t1)), "gpx_gemv")
+        _lib.check(lib.gpx_gemv(rt.h, 0, n, n, ptr(UtU), UtU.shape[1], ptr(t1), ptr(t2)), "gpx_gemv")
+        b = self.nu_tilde - rt.download(t2[:n])
+        kind, sigma, beta = self.cov.gram_params(self.dim)
+        beta_arr, beta_p = _lib.host_doubles(beta)
+        dX = rt.upload_matrix(np.ascontiguousarray(self.Xtr, dtype=np.float64))
+        ng = 2 + len(beta_arr)
+
+        def traces(alpha_d, M):
+            out = (C.c_double * ng)()
+            _lib.check(lib.gpx_grad_trace(rt.h, kind, ptr(dX), n, dX.shape[1], self.dim, sigma, beta_p, ptr(alpha_d),
+                                          ptr(M), M.shape[1], C.cast(out, C.POINTER(C.c_double))), "gpx_grad_trace")
+            return np.array(list(out))
+
+        # 1/2 sum (b b^T) o dK: the trace kernel with a zero matrix in place of Ky^-1 (dv["V"] is free after the fit)
+        Z = dv["V"]
+        Z.zero_()
+        first = traces(rt.upload_vector(b), Z)
+        # 1/2 sum (U^T U) o dK: the same kernel with alpha = 0 returns its negative
+        second = -traces(rt.vector(n, zero=True), UtU)
+        pair = lambda i: [first[i], second[i]]
+        cov_beta = pair(2) if len(beta_arr) == 1 else [first[2:].copy(), second[2:].copy()]
+        out = {"cov__sigma": pair(1), "cov__beta": cov_beta}
+        return {k: v if splitted_terms else np.sum(v) for k, v in out.items()}
+
+    def _UtU_device(self, dv):
+        """U^T U for U = L^-1 diag(S) (expectation_propagation.py:162) as a device matrix (full, symmetric)."""
+        rt, n = dv["rt"], dv["n"]
+        rt.bind_stream()
+        U = dv["V"]                                   # n x n scratch of the recompute, free after the fit
+        U.zero_()
+        U[:n, :n].diagonal().copy_(rt.torch.from_numpy(np.ascontiguousarray(self.S.ravel(), dtype=np.float64)))
+        _lib.check(rt.lib.gpx_trsm(rt.h, 0, n, n, ptr(dv["B"]), dv["B"].shape[1], ptr(dv["dinv"]), ptr(U), U.shape[1]),
+                   "gpx_trsm")
         UtU = rt.matrix(n, n)
         _lib.check(rt.lib.gpx_gemm(rt.h, 1, 0, n, n, n, 1.0, ptr(U), U.shape[1], ptr(U), U.shape[1], 0.0,
                                    ptr(UtU), UtU.shape[1]), "gpx_gemm")
-        UtU_h = rt.download(UtU[:n, :n])
+        return UtU
+
+    def _grad_log_marginal_likelihood(self, K, K_grads):
+        """expectation_propagation.py:161-167 for arbitrary host derivative matrices (Distillation's Kronecker
+        planes): U^T U on the device, the contractions with the caller's planes on the host."""
+        dv = self._dv
+        rt = dv["rt"]
+        n = dv["n"]          # size of K: self.n here, 2 self.n under distillation.py
+        UtU_h = rt.download(self._UtU_device(dv)[:n, :n])
         K = K + eps * np.eye(n)
         b = self.nu_tilde - UtU_h @ (K @ self.nu_tilde)
         out = {}

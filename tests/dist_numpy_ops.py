@@ -92,6 +92,10 @@ class NumpyOps:
         n, m = A.shape
         y.numpy()[:n] = A.numpy() @ x.numpy()[:m]
 
+    def colsumsq(self, V, base, var):
+        m = V.shape[1]
+        var.numpy()[:m] = base - (V.numpy() ** 2).sum(axis=0)
+
     def grad_trace_slab(self, kind, sigma, beta, X, d, alpha, slab, row_off, col_off):
         """Restatement of the slab sums: entries on/below the global diagonal, weight 2 off it."""
         Xn = X.numpy()[:, :d]

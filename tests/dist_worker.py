@@ -1,5 +1,5 @@
 """Shared launcher for the multi-rank tests: spawns `world` processes that run
-gaussian_process_amd.distributed.DistributedGP under gloo, with either the NumPy test double
+gaussian_process_amd.distributed.DistributedGP (2-D block-cyclic, sharded) under gloo, with either the NumPy test double
 (CPU, tests/test_dist_cpu.py) or the real libgpx kernels on cuda:0 (tests/test_gpu_dist.py; all
 ranks share the one GPU of the box), and compares every rank's results with the oracle."""
 import os
@@ -34,7 +34,11 @@ def worker(rank, world, port, case, q):
         from gaussian_process_amd.distributed import DistributedGP, GpuOps
         from oracle import gp_oracle as orc
         torch.set_num_threads(2)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if case.get("backend") == "nccl":
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         n, m, d, block, kind = case["n"], case["m"], case["d"], case["block"], case["kind"]
         X, y, Xs, _ = orc.synthetic_ard(n, m, d, seed=case.get("seed", 3))
         sigma, noise = 1.3, case.get("noise", 0.05)
@@ -49,8 +53,10 @@ def worker(rank, world, port, case, q):
             from dist_numpy_ops import NumpyOps
             ops = NumpyOps()
         host = lambda x: x.detach().cpu().numpy()
+        grid = tuple(case["grid"]) if case.get("grid") else None
         gp = DistributedGP(ops, dist, rank, world, block=block, update_k=case.get("update_k", 2048),
-                           grad_block=case.get("grad_block", 256), row_chunk=case.get("row_chunk"))
+                           grad_block=case.get("grad_block", 256), grid=grid,
+                           force_collectives=bool(case.get("force_collectives")))
         out = {"rank": rank}
         if case.get("estimator"):
             # the reference's estimator interface over the ranks (distributed_regression.py)
@@ -58,8 +64,8 @@ def worker(rank, world, port, case, q):
             from gaussian_process_amd.distributed_regression import DistributedGaussianProcessRegression as DGPR
             if not case.get("gpu"):
                 DGPR.ops_factory = staticmethod(lambda: ops)
-            DGPR.dist_options = dict(block=block, update_k=case.get("update_k", 2048), grad_block=256,
-                                     row_chunk=case.get("row_chunk"))
+            DGPR.dist_options = dict(block=block, update_k=case.get("update_k", 2048), grad_block=256, grid=grid,
+                                     force_collectives=bool(case.get("force_collectives")))
             cov = ARD(sigma=sigma, beta=beta.copy()) if kind == "ard" else RBF(sigma=sigma, beta=float(beta[0]))
             est = DGPR(cov, sigma=noise)
             est.fit(X, y)
@@ -74,7 +80,8 @@ def worker(rank, world, port, case, q):
             out.update(lml=abs(lml - lml_o) / abs(lml_o), alpha=rel(est.alpha_(), alpha_o), mean=rel(mean, mean_o),
                        cov=rel(cov_m, cov_o), keys=list(g.keys()),
                        grad=max(float(np.abs(g[k] - go[k]).max()) for k in go) / gscale,
-                       mean_only=rel(est.predict(Xs), mean_o))
+                       mean_only=rel(est.predict(Xs), mean_o),
+                       var=rel(est.predict_with_variance(Xs, full_cov=False)[1], np.diagonal(cov_o)))
             before = lml
             est.empirical_bayes()
             out["eb_gain"] = est.log_marginal_likelihood() - before
@@ -94,25 +101,30 @@ def worker(rank, world, port, case, q):
             go, _ = orc.gpr_grad(kind, X, y, sigma, beta, noise, spd_inverse=True)
             go = np.concatenate([go["sigma"], go["cov__sigma"], go["cov__beta"]])
             out["grad"] = float(np.abs(g - go).max() / np.abs(go).max())
-            L = np.tril(host(gp.A[:n, :n]))
+            mean_d, var_d = gp.predict(Xs, full_cov=False)
+            L = gp.gather_lower()
             Lo = orc.gpr_factor(kind, X, sigma, beta, noise)
             lml_o, a_o, _ = orc.gpr_lml(kind, X, y, sigma, beta, noise, L=Lo)
             mean_o, cov_o = orc.gpr_predict(kind, X, y, Xs, sigma, beta, noise, L=Lo)
             rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
             out.update(L=rel(L, Lo), lml=abs(lml - lml_o) / abs(lml_o), alpha=rel(host(gp.alpha)[:n], orc.gpr_alpha(Lo, y)),
-                       mean=rel(mean, mean_o), cov=rel(cov, cov_o), shapes=(mean.shape, cov.shape))
+                       mean=rel(mean, mean_o), cov=rel(cov, cov_o), shapes=(mean.shape, cov.shape),
+                       var=max(rel(var_d, np.diagonal(cov_o)), rel(mean_d, mean_o)), mem=gp.resident_bytes,
+                       grid=(gp.P, gp.Q))
             # the diagonal-block inverses every rank keeps must match the factor it keeps
             nb = 128
             worst = 0.0
+            dinv_all = gp.gather_dinv()
             for i, b0 in enumerate(range(0, n, nb)):
                 b1 = min(n, b0 + nb)
-                blk = host(gp.dinv[i * nb * nb:(i + 1) * nb * nb]).reshape(nb, nb)[: b1 - b0, : b1 - b0]
+                blk = dinv_all[i][: b1 - b0, : b1 - b0]
                 worst = max(worst, float(np.abs(blk @ Lo[b0:b1, b0:b1] - np.eye(b1 - b0)).max()))
             out["dinv"] = worst
-            out["res"] = gp.residual()          # last: it overwrites the factor
+            out["res"] = gp.residual(chunk=case.get("res_chunk", 2048))
         q.put(out)
         dist.barrier()
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
     except Exception:
         q.put({"rank": rank, "error": traceback.format_exc()})
 
@@ -162,3 +174,39 @@ def run(world, case):
     return sorted(outs, key=lambda o: o["rank"])
 
 
+def _nccl_world1():
+    """RCCL rehearsal in THIS process: backend "nccl", world size 1, collectives forced on the one-rank
+    groups -- asynchronous broadcasts / all-gathers, the forwarding stream and the stream waits of the
+    production branch run for real (tests/test_gpu_dist.py::test_rccl_backend_world1_matches_oracle)."""
+    import queue
+
+    class Q:
+        def __init__(self):
+            self.items = []
+
+        def put(self, x):
+            self.items.append(x)
+
+    for case in (dict(n=2500, m=37, d=8, block=128, kind="ard", gpu=True, backend="nccl", force_collectives=True,
+                      update_k=512, grad_block=512),
+                 dict(n=1100, m=30, d=3, block=256, kind="ard", gpu=True, backend="nccl", force_collectives=True,
+                      update_k=256, grad_block=256),
+                 dict(n=600, m=21, d=2, block=128, kind="ard", gpu=True, backend="nccl", force_collectives=True,
+                      estimator=True)):
+        q = Q()
+        worker(0, 1, _free_port(), case, q)
+        o = q.items[0]
+        assert "error" not in o, o.get("error")
+        print(o, flush=True)
+        if case.get("estimator"):
+            assert o["lml"] < 1e-11 and o["alpha"] < 1e-9 and o["grad"] < 1e-8 and o["mean"] < 1e-9 and o["cov"] < 1e-9, o
+            assert o["var"] < 1e-9 and o["eb_gain"] > 0.0, o
+        else:
+            assert o["L"] < 1e-12 and o["dinv"] < 1e-9 and o["lml"] < 1e-11 and o["alpha"] < 1e-9 and o["grad"] < 1e-9, o
+            assert o["mean"] < 1e-9 and o["cov"] < 1e-9 and o["var"] < 1e-9 and o["res"] < 1e-10, o
+    print("NCCL1 OK", flush=True)
+
+
+if __name__ == "__main__":
+    if "--nccl1" in sys.argv:
+        _nccl_world1()

@@ -15,7 +15,9 @@ Cases:
   g1_rbf1d_n200    same generator at n=200 (BASELINE config 1 wording)
   g2_ard2d         examples/ARD_regression_2d.ipynb cells 2-5 (n_train=100) incl. empirical Bayes
   g3_ard8_n{256,1024,4096}   synthetic ARD d=8 workload of SURVEY 8(d), m=256
-  g4_ep_moons_n{50,200}      examples/expectation_propagation.ipynb split; _ep(K, shuffle=False)
+  g4_ep_moons_n{50,200,512,1024}  examples/expectation_propagation.ipynb split; _ep(K, shuffle=False)
+                             (n = 512, 1024 cross the 256-site block of the device sweep; K is not stored
+                             there, only sampled entries)
   g5_distill_rho{100,050,000}  examples/distillation_illustration.ipynb cells 2-5 (n_train=50),
                              rho = 1, 0.5, 0: _ep(kron(Kt, K_), fixed soft-label sites, shuffle=False)
                              and the public fit() under np.random.seed(0)
@@ -41,6 +43,10 @@ from oracle.gp_oracle import synthetic_ard  # noqa: E402  (input generator only)
 
 
 ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
+
+
+def want(name):
+    return name.startswith(ONLY) or ONLY.startswith(name)
 
 
 def save(name, **kw):
@@ -83,8 +89,9 @@ def regression_case(name, gp, X, y, Xs, store_K=True, extra=None):
 
 def main():
     warnings.simplefilter("ignore")
+    from sklearn.model_selection import train_test_split
     # ---- G1: regression_1d notebook ------------------------------------
-    for n in (15, 200):
+    for n in (15, 200) if want("g1") else ():
         X, y = generate_gp(n_samples=n, kernel=RBF(beta=1.), random_state=1, noise=0.1)
         Xs = np.linspace(-3, 3).reshape(-1, 1)
         gp = GaussianProcessRegression(cov=RBF(), sigma=0.1)
@@ -98,23 +105,23 @@ def main():
         regression_case("g1_rbf1d_n%d" % n, gp, X, y, Xs, extra=extra)
 
     # ---- G2: ARD_regression_2d notebook --------------------------------
-    from sklearn.model_selection import train_test_split
-    X, y = generate_gp(n_samples=200, n_features=2, kernel=ARD(beta=[1, 3]), random_state=0, noise=0.01)
-    Xtr, Xte, ytr, yte = train_test_split(X, y, train_size=0.5, random_state=0)
-    gp = GaussianProcessRegression(cov=ARD(beta=[1, 1]))
-    gp.fit(Xtr, ytr)
-    rmse0 = np.sqrt(np.mean((gp.predict(Xte) - yte) ** 2))
-    g2 = GaussianProcessRegression(cov=ARD(beta=[1, 1]))
-    g2.fit(Xtr, ytr)
-    g2.empirical_bayes()
-    rmse1 = np.sqrt(np.mean((g2.predict(Xte) - yte) ** 2))
-    regression_case("g2_ard2d", GaussianProcessRegression(cov=ARD(beta=[1, 1])), Xtr, ytr, Xte,
-                    extra=dict(yte=yte, rmse_before=rmse0, rmse_after=rmse1,
-                               eb_beta=g2.cov.beta, eb_cov_sigma=g2.cov.sigma, eb_noise=g2.sigma,
-                               eb_lml=g2.log_marginal_likelihood()))
+    if want("g2"):
+        X, y = generate_gp(n_samples=200, n_features=2, kernel=ARD(beta=[1, 3]), random_state=0, noise=0.01)
+        Xtr, Xte, ytr, yte = train_test_split(X, y, train_size=0.5, random_state=0)
+        gp = GaussianProcessRegression(cov=ARD(beta=[1, 1]))
+        gp.fit(Xtr, ytr)
+        rmse0 = np.sqrt(np.mean((gp.predict(Xte) - yte) ** 2))
+        g2 = GaussianProcessRegression(cov=ARD(beta=[1, 1]))
+        g2.fit(Xtr, ytr)
+        g2.empirical_bayes()
+        rmse1 = np.sqrt(np.mean((g2.predict(Xte) - yte) ** 2))
+        regression_case("g2_ard2d", GaussianProcessRegression(cov=ARD(beta=[1, 1])), Xtr, ytr, Xte,
+                        extra=dict(yte=yte, rmse_before=rmse0, rmse_after=rmse1,
+                                   eb_beta=g2.cov.beta, eb_cov_sigma=g2.cov.sigma, eb_noise=g2.sigma,
+                                   eb_lml=g2.log_marginal_likelihood()))
 
     # ---- G3: synthetic ARD d=8 ------------------------------------------
-    for n in (256, 1024, 4096):
+    for n in (256, 1024, 4096) if want("g3") else ():
         X, y, Xs, beta = synthetic_ard(n, m=256, d=8, seed=0, noise=0.1)
         gp = GaussianProcessRegression(cov=ARD(sigma=1.0, beta=beta), sigma=0.1)
         regression_case("g3_ard8_n%d" % n, gp, X, y, Xs, store_K=(n == 256),
@@ -122,10 +129,15 @@ def main():
 
     # ---- G4: EP on make_moons -------------------------------------------
     from sklearn.datasets import make_moons
-    for ntot in (100, 400):
+    for ntot in (100, 400, 1024, 2048):
+        name = "g4_ep_moons_n%d" % (ntot // 2)
+        if not want(name):
+            continue
         X, y = make_moons(ntot, noise=0.1, random_state=0)
         y = 2 * y - 1
         Xtr, Xte, ytr, yte = train_test_split(X, y, train_size=0.5, random_state=0)
+        if ntot > 400:
+            Xte, yte = Xte[:200], yte[:200]
         ep = GaussianProcessExpectationPropagation(RBF())
         ep.Xtr, ep.ytr = Xtr, ytr
         ep.n, ep.dim = Xtr.shape
@@ -135,7 +147,10 @@ def main():
         pm, pv = ep.posterior(Xte)
         dec = ep.decision_function(Xte)
         grads = ep.grad_log_marginal_likelihood()
-        save("g4_ep_moons_n%d" % (ntot // 2), Xtr=Xtr, ytr=ytr, Xte=Xte, yte=yte, K=K,
+        small = ntot <= 400
+        idx = np.random.default_rng(7).integers(0, ep.n, size=(512, 2))
+        save(name, Xtr=Xtr, ytr=ytr, Xte=Xte, yte=yte, K=K if small else np.zeros(0),
+             K_idx=idx, K_samples=K[idx[:, 0], idx[:, 1]], K_sum=K.sum(),
              tau=ep.tau_tilde, nu=ep.nu_tilde, mu=ep.mu, diagSigma=np.diag(ep.Sigma),
              Sigma=ep.Sigma if ntot == 100 else np.zeros(0),
              diagL=np.diag(ep.L), z=ep.z, lml=lml, post_mean=pm, post_var=pv, decision=dec,
@@ -147,7 +162,7 @@ def main():
     y = np.sign(s)
     Xtr, Xte, ytr, yte, s_tr, s_te = train_test_split(X, y, s, train_size=0.5, random_state=0)
     Xgrid = np.linspace(-3, 3).reshape(-1, 1)
-    for rho in (1.0, 0.5, 0.0):
+    for rho in (1.0, 0.5, 0.0) if want("g5") else ():
         gpd = GaussianProcessDistillation(cov=RBF(1, 1), sigma=0.01, rho=rho)
         gpd.Xtr, gpd.ytr, gpd.str = Xtr, ytr, s_tr
         gpd.n, gpd.dim = Xtr.shape

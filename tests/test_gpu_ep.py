@@ -8,16 +8,23 @@ from conftest import load_golden, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["g4_ep_moons_n50", "g4_ep_moons_n200"])
+@pytest.mark.parametrize("name", ["g4_ep_moons_n50", "g4_ep_moons_n200", "g4_ep_moons_n512", "g4_ep_moons_n1024"])
 def test_ep_matches_reference(name):
+    """n = 512 and 1024 cross the 256-site block of the delayed rank-1 updates (gpx_ep_sweep) against the
+    REFERENCE itself, not only the oracle."""
     from gaussian_process_amd import GaussianProcessExpectationPropagation, RBF
     g = load_golden(name)
     ep = GaussianProcessExpectationPropagation(RBF())
     ep.Xtr, ep.ytr = g["Xtr"], g["ytr"]
     ep.n, ep.dim = g["Xtr"].shape
     K = ep.cov(ep.Xtr).K
-    assert relerr(K, g["K"]) < 1e-13
-    ep._ep(g["K"], shuffle=False)
+    if g["K"].size:
+        assert relerr(K, g["K"]) < 1e-13
+        K = g["K"]
+    else:                 # large cases hold sampled entries of the reference's K only
+        idx = g["K_idx"]
+        assert relerr(K[idx[:, 0], idx[:, 1]], g["K_samples"]) < 1e-13
+    ep._ep(K, shuffle=False)
     assert relerr(ep.tau_tilde, g["tau"]) < 1e-8
     assert relerr(ep.nu_tilde, g["nu"]) < 1e-8
     assert relerr(ep.mu, g["mu"]) < 1e-8
