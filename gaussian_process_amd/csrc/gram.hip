@@ -11,6 +11,7 @@
 // and every lane two adjacent columns, so one store instruction writes 1 KiB of one row
 // (16 B per lane, fully coalesced).  The two X2 rows of a lane live in registers (pre-scaled by
 // sqrt(beta_k)); the X1 rows are read from LDS at wave-uniform addresses (broadcast).
+#include <cstdlib>
 #include <type_traits>
 
 #include "gpx_internal.h"
@@ -208,35 +209,47 @@ struct TraceArgs {
 
 constexpr int TR_MAXACC = GPX_MAXD + 2;
 
+// One workgroup owns TR_SUBS row sub-tiles (64 rows each) of one 128-column strip: the per-lane X
+// columns and alpha stay in registers across them, the accumulators are reduced once per workgroup
+// (a 64 x 128 tile per workgroup spent a third of its time in prologue + reduction and left
+// 8x as many partials for the final pass).
 template <int D>
-__global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs a) {
-  __shared__ double sx1[GT_ROWS * GPX_MAXD];
-  __shared__ double sal[GT_ROWS];
+struct TraceCfg {
+  static constexpr int SUBS = D > 0 ? 8 : 4;                 // LDS: SUBS * 64 * d doubles (32 KiB / 64 KiB)
+  static constexpr int DD = D > 0 ? D : GPX_MAXD;
+};
+
+template <int D>
+__global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs a, int band_row0) {
+  constexpr int SUBS = TraceCfg<D>::SUBS, DD = TraceCfg<D>::DD;
+  __shared__ double sx1[SUBS * GT_ROWS * DD];
+  __shared__ double sal[SUBS * GT_ROWS];
   __shared__ double sred[4][TR_MAXACC];
   const int d = D > 0 ? D : a.d;
   const int nacc = 2 + a.nbeta;
-  const int r0 = blockIdx.y * GT_ROWS, c0 = blockIdx.x * GT_COLS;
+  const int rb = band_row0 + blockIdx.y * (SUBS * GT_ROWS), c0 = blockIdx.x * GT_COLS;
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-  const bool skip = a.coff + c0 > a.roff + r0 + GT_ROWS - 1;   // tile strictly above the diagonal
+  const int rows_here = min(SUBS * GT_ROWS, a.nr - rb);
+  // every sub-tile strictly above the diagonal: nothing to add
+  const bool skip = rows_here <= 0 || a.coff + c0 > a.roff + rb + rows_here - 1;
 
   // acc[0]: sum A_ii (diag)   acc[1]: sum w A_ij K_ij   acc[2+k]: sum w A_ij K_ij z-diff_k^2
-  double acc[2 + (D > 0 ? D : GPX_MAXD)];
+  double acc[2 + DD];
 #pragma unroll
-  for (int q = 0; q < 2 + (D > 0 ? D : GPX_MAXD); ++q) acc[q] = 0.0;
+  for (int q = 0; q < 2 + DD; ++q) acc[q] = 0.0;
 
   if (!skip) {
-    for (int e = t; e < GT_ROWS * d; e += GT_THREADS) {
+    for (int e = t; e < rows_here * d; e += GT_THREADS) {
       const int r = e / d, k = e - r * d;
-      const int lr = r0 + r;
-      sx1[r * d + k] = lr < a.nr ? a.X[(long)(a.roff + lr) * a.ldx + k] * a.sb.b[k] : 0.0;
+      sx1[e] = a.X[(long)(a.roff + rb + r) * a.ldx + k] * a.sb.b[k];
     }
-    if (t < GT_ROWS) sal[t] = (r0 + t) < a.nr ? a.alpha[a.roff + r0 + t] : 0.0;
+    for (int e = t; e < rows_here; e += GT_THREADS) sal[e] = a.alpha[a.roff + rb + e];
     const int c = c0 + 2 * lane;          // local column
     const int gc = a.coff + c;            // global column
-    double z0[D > 0 ? D : GPX_MAXD], z1[D > 0 ? D : GPX_MAXD];
+    double z0[DD], z1[DD];
 #pragma unroll
-    for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
+    for (int k = 0; k < DD; ++k) {
       if (k < d) {
         z0[k] = c < a.nc ? a.X[(long)gc * a.ldx + k] * a.sb.b[k] : 0.0;
         z1[k] = c + 1 < a.nc ? a.X[(long)(gc + 1) * a.ldx + k] * a.sb.b[k] : 0.0;
@@ -245,49 +258,92 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
     const double al0 = c < a.nc ? a.alpha[gc] : 0.0;
     const double al1 = c + 1 < a.nc ? a.alpha[gc + 1] : 0.0;
     __syncthreads();
-    for (int rr = 0; rr < 16; ++rr) {
-      const int r = wid * 16 + rr;
-      const int lr = r0 + r;
-      if (lr >= a.nr) break;
-      const int gr = a.roff + lr;
-      if (gc > gr || c >= a.nc) continue;  // both columns above the diagonal / outside the slab
-      const double* src = a.Kinv + (long)lr * a.ldk + c;
-      double q0 = 0.0, q1 = 0.0;
-      const bool v1 = (gc + 1 <= gr) && (c + 1 < a.nc);
-      if (v1) {
-        const v2d q = *reinterpret_cast<const v2d*>(src);
-        q0 = q[0];
-        q1 = q[1];
-      } else {
-        q0 = src[0];
-      }
-      const double ai = sal[r];
-      double s0 = 0.0, s1 = 0.0;
-      double e0[D > 0 ? D : GPX_MAXD], e1[D > 0 ? D : GPX_MAXD];
+    for (int sub = 0; sub < SUBS; ++sub) {
+      const int r0 = rb + sub * GT_ROWS;
+      if (r0 >= a.nr) break;
+      if (a.coff + c0 > a.roff + r0 + GT_ROWS - 1) continue;   // tile strictly above the diagonal
+      const double* xs = sx1 + sub * GT_ROWS * d;
+      const double* as = sal + sub * GT_ROWS;
+      // interior: whole tile strictly below the diagonal and inside the slab -> weight 2, no predicates
+      const bool interior = a.roff + r0 >= a.coff + c0 + GT_COLS && r0 + GT_ROWS <= a.nr && c0 + GT_COLS <= a.nc;
+      if (interior) {
+        const double* src = a.Kinv + (long)(r0 + wid * 16) * a.ldk + c;
+#pragma unroll 2
+        for (int rr = 0; rr < 16; ++rr) {
+          const v2d q = *reinterpret_cast<const v2d*>(src);
+          src += a.ldk;
+          const int r = wid * 16 + rr;
+          const double ai = as[r];
+          double s0 = 0.0, s1 = 0.0;
+          double e0[DD], e1[DD];
 #pragma unroll
-      for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
-        if (k < d) {
-          const double x = sx1[r * d + k];
-          const double d0 = x - z0[k], d1 = x - z1[k];
-          e0[k] = d0 * d0;
-          e1[k] = d1 * d1;
-          s0 += e0[k];
-          s1 += e1[k];
+          for (int k = 0; k < DD; ++k) {
+            if (k < d) {
+              const double x = xs[r * d + k];
+              const double d0 = x - z0[k], d1 = x - z1[k];
+              e0[k] = d0 * d0;
+              e1[k] = d1 * d1;
+              s0 += e0[k];
+              s1 += e1[k];
+            }
+          }
+          const double w0 = 2.0 * (ai * al0 - q[0]) * exp_nonpos(-0.5 * s0);
+          const double w1 = 2.0 * (ai * al1 - q[1]) * exp_nonpos(-0.5 * s1);
+          acc[1] += w0 + w1;
+          if (a.nbeta == 1) {
+            acc[2] += w0 * s0 + w1 * s1;
+          } else {
+#pragma unroll
+            for (int k = 0; k < DD; ++k)
+              if (k < d) acc[2 + k] += w0 * e0[k] + w1 * e1[k];
+          }
         }
+        continue;
       }
-      const double A0 = ai * al0 - q0;
-      const double A1 = v1 ? ai * al1 - q1 : 0.0;
-      const double w0 = (gc == gr ? 1.0 : 2.0) * A0 * exp_nonpos(-0.5 * s0);
-      const double w1 = v1 ? (gc + 1 == gr ? 1.0 : 2.0) * A1 * exp_nonpos(-0.5 * s1) : 0.0;
-      if (gc == gr) acc[0] += A0;
-      if (v1 && gc + 1 == gr) acc[0] += A1;
-      acc[1] += w0 + w1;
-      if (a.nbeta == 1) {
-        acc[2] += w0 * s0 + w1 * s1;  // RBF: sum_k beta (x-x')^2 ; divided by beta on the host
-      } else {
+      for (int rr = 0; rr < 16; ++rr) {
+        const int r = wid * 16 + rr;
+        const int lr = r0 + r;
+        if (lr >= a.nr) break;
+        const int gr = a.roff + lr;
+        if (gc > gr || c >= a.nc) continue;  // both columns above the diagonal / outside the slab
+        const double* src = a.Kinv + (long)lr * a.ldk + c;
+        double q0 = 0.0, q1 = 0.0;
+        const bool v1 = (gc + 1 <= gr) && (c + 1 < a.nc);
+        if (v1) {
+          const v2d q = *reinterpret_cast<const v2d*>(src);
+          q0 = q[0];
+          q1 = q[1];
+        } else {
+          q0 = src[0];
+        }
+        const double ai = as[r];
+        double s0 = 0.0, s1 = 0.0;
+        double e0[DD], e1[DD];
 #pragma unroll
-        for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k)
-          if (k < d) acc[2 + k] += w0 * e0[k] + w1 * e1[k];
+        for (int k = 0; k < DD; ++k) {
+          if (k < d) {
+            const double x = xs[r * d + k];
+            const double d0 = x - z0[k], d1 = x - z1[k];
+            e0[k] = d0 * d0;
+            e1[k] = d1 * d1;
+            s0 += e0[k];
+            s1 += e1[k];
+          }
+        }
+        const double A0 = ai * al0 - q0;
+        const double A1 = v1 ? ai * al1 - q1 : 0.0;
+        const double w0 = (gc == gr ? 1.0 : 2.0) * A0 * exp_nonpos(-0.5 * s0);
+        const double w1 = v1 ? (gc + 1 == gr ? 1.0 : 2.0) * A1 * exp_nonpos(-0.5 * s1) : 0.0;
+        if (gc == gr) acc[0] += A0;
+        if (v1 && gc + 1 == gr) acc[0] += A1;
+        acc[1] += w0 + w1;
+        if (a.nbeta == 1) {
+          acc[2] += w0 * s0 + w1 * s1;  // RBF: sum_k beta (x-x')^2 ; divided by beta on the host
+        } else {
+#pragma unroll
+          for (int k = 0; k < DD; ++k)
+            if (k < d) acc[2 + k] += w0 * e0[k] + w1 * e1[k];
+        }
       }
     }
   }
@@ -302,23 +358,23 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
   if (t < nacc) a.partials[(size_t)bid * nacc + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
 }
 
-// Final fixed-order reduction of [nblocks][nacc] partials -> out[nacc]; one workgroup.
+// Final fixed-order reduction of [nblocks][nacc] partials -> out[nacc]: one workgroup per accumulator
+// (they run side by side; one workgroup doing all of them in turn took 3.8 ms at n = 65536).
+// accumulate != 0 adds to out (the later row bands of a launch split to fit the scratch).
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* partials, size_t nblocks,
-                                                                int nacc, double* out) {
+                                                                int nacc, double* out, int accumulate) {
   __shared__ double sm[1024];
   const int t = threadIdx.x;
-  for (int q = 0; q < nacc; ++q) {
-    double v = 0.0;
-    for (size_t b = t; b < nblocks; b += 1024) v += partials[b * nacc + q];
-    sm[t] = v;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-      if (t < s) sm[t] += sm[t + s];
-      __syncthreads();
-    }
-    if (t == 0) out[q] = sm[0];
+  const int q = blockIdx.x;
+  double v = 0.0;
+  for (size_t b = t; b < nblocks; b += 1024) v += partials[b * nacc + q];
+  sm[t] = v;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (t < s) sm[t] += sm[t + s];
     __syncthreads();
   }
+  if (t == 0) out[q] = accumulate ? out[q] + sm[0] : sm[0];
 }
 
 template <typename F>
@@ -373,18 +429,35 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int n
   a.X = X; a.ldx = ldx; a.nr = nr; a.nc = nc; a.roff = roff; a.coff = coff; a.d = d; a.nbeta = nbeta;
   a.sigma = sigma; a.alpha = alpha; a.Kinv = Kinv; a.ldk = ldk; a.partials = red;
   for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(hb.b[k]) : 0.0;
-  dim3 grid((nc + GT_COLS - 1) / GT_COLS, (nr + GT_ROWS - 1) / GT_ROWS);
-  const size_t nblocks = (size_t)grid.x * grid.y;
   const int nacc = 2 + nbeta;
-  if (nblocks * nacc > red_elems) {
-    gpx_set_error("grad_trace: reduction scratch too small for a %d x %d slab", nr, nc);
-    return GPX_ENOMEM;
-  }
+  int rc = 0;
   dispatch_d(d, [&](auto D) {
-    hipLaunchKernelGGL((grad_trace_kernel<decltype(D)::value>), grid, dim3(GT_THREADS), 0, s, a);
+    constexpr int DV = decltype(D)::value;
+    constexpr int rows_per_block = TraceCfg<DV>::SUBS * GT_ROWS;
+    const unsigned gx = (nc + GT_COLS - 1) / GT_COLS;
+    const size_t gy_all = (nr + rows_per_block - 1) / rows_per_block;
+    // row bands: as many block rows per launch as the partials scratch holds (one band unless n * d is huge)
+    size_t gy_band = red_elems / ((size_t)gx * nacc);
+    if (gy_band == 0) {
+      gpx_set_error("grad_trace: reduction scratch too small for a strip of %d columns", nc);
+      rc = GPX_ENOMEM;
+      return;
+    }
+    static const long band_cap = [] {
+      const char* e = getenv("GPX_TRACE_BAND_ROWS");   // development/test override: block rows per band
+      return e ? atol(e) : 0L;
+    }();
+    if (band_cap > 0 && (size_t)band_cap < gy_band) gy_band = (size_t)band_cap;
+    if (gy_band > gy_all) gy_band = gy_all;
+    for (size_t y0 = 0; y0 < gy_all; y0 += gy_band) {
+      const unsigned gy = (unsigned)(gy_all - y0 < gy_band ? gy_all - y0 : gy_band);
+      hipLaunchKernelGGL((grad_trace_kernel<DV>), dim3(gx, gy), dim3(GT_THREADS), 0, s, a,
+                         (int)(y0 * rows_per_block));
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(nacc), dim3(1024), 0, s, red, (size_t)gx * gy, nacc, out_dev,
+                         y0 > 0 ? 1 : 0);
+    }
   });
-  GPX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, red, nblocks, nacc, out_dev);
+  if (rc != 0) return rc;
   GPX_HIP(hipGetLastError());
   return 0;
 }

@@ -267,8 +267,11 @@ def test_syrk_sub_gemv(rt, n, m):
     assert relerr(rt.download(dw[:n]), V @ z) < 1e-13
 
 
-@pytest.mark.parametrize("kind,d,n", [("ard", 8, 300), ("rbf", 2, 129), ("ard", 3, 64)])
+@pytest.mark.parametrize("kind,d,n", [("ard", 8, 300), ("rbf", 2, 129), ("ard", 3, 64), ("ard", 8, 1500), ("ard", 32, 700),
+                                      ("ard", 5, 1100), ("rbf", 8, 1030)])
 def test_grad_trace_matches_oracle(rt, kind, d, n):
+    """d = 32 is GPX_MAXD (generic-dimension kernel, 4 row sub-tiles per workgroup); n = 1500 / 1100 / 1030 span
+    several 512-row (256-row) workgroup strips with ragged edges."""
     from gaussian_process_amd import _lib
     rng = np.random.default_rng(n)
     X = rng.uniform(-3, 3, (n, d))
@@ -330,3 +333,40 @@ def test_trmm_lower_times_matrix(rt, n, m):
     dB, dO = up(rt, B), rt.matrix(n, m)
     ok(rt.lib.gpx_trmm(rt.h, n, m, P(dL), dL.shape[1], P(dB), dB.shape[1], P(dO), dO.shape[1]))
     assert relerr(down(rt, dO, n, m), L @ B) < 1e-13
+
+
+def test_grad_trace_row_bands_give_the_same_sums():
+    """When the per-workgroup partials of a large n x d would not fit the reduction scratch the launch is
+    split into row bands whose sums accumulate; forced here with one block row per band (development
+    override read at first use, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from gaussian_process_amd import _lib
+from gaussian_process_amd.device import runtime, ptr
+rt = runtime(); rt.bind_stream()
+rng = np.random.default_rng(5)
+n, d = 1700, 8
+X = rng.uniform(-3, 3, (n, d)); al = rng.standard_normal(n)
+M = rng.standard_normal((n, n)); M = np.tril(M @ M.T / n)
+beta = rng.uniform(0.05, 1.0, d)
+dX, dal, dM = rt.upload_matrix(X), rt.upload_vector(al), rt.upload_matrix(M)
+barr, bp = _lib.host_doubles(beta)
+out = (C.c_double * (2 + d))()
+_lib.check(rt.lib.gpx_grad_trace(rt.h, 1, ptr(dX), n, dX.shape[1], d, 1.3, bp, ptr(dal), ptr(dM), dM.shape[1],
+                                 C.cast(out, C.POINTER(C.c_double))), "grad_trace")
+print(" ".join(repr(v) for v in out))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for band in ("", "1"):
+        env = dict(os.environ)
+        env.pop("GPX_TRACE_BAND_ROWS", None)
+        if band:
+            env["GPX_TRACE_BAND_ROWS"] = band
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.array([float(v) for v in r.stdout.strip().splitlines()[-1].split()]))
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-12 * np.abs(outs[0]).max()
