@@ -171,9 +171,8 @@ __host__ __device__ __forceinline__ void super_coords(unsigned st, int tiles_m, 
 // (idx / 64) * 8 + xcd, so the 64 workgroups resident on one XCD work on one 8 x 8 super-tile
 // (8 A panels + 8 B panels in its private L2) and super-tiles are dealt round-robin over the XCDs
 // (balanced also when the work per tile varies, as with triangular operands).
-__device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower, unsigned nsuper, unsigned bid0,
+__device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower, unsigned nsuper, unsigned bid,
                                              int order, int& bi, int& bj) {
-  const unsigned bid = blockIdx.x + bid0;
   if (nsuper == 0) {  // small launch: one block per tile, linear (row-major / packed lower) order
     if (lower) {
       unsigned r = (unsigned)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
@@ -215,7 +214,13 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
   __shared__ __attribute__((aligned(16))) double smem[2 * (TA::ELEMS + TB::ELEMS)];
 
   int bi, bj;
-  if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bid0, order, bi, bj)) return;
+  unsigned bid = blockIdx.x + bid0;
+  int part = 0;
+  if (g.split_s > 1) {   // split-K tail: split_s consecutive workgroups share one tile
+    part = (int)(bid % (unsigned)g.split_s);
+    bid = g.split_tile0 + bid / (unsigned)g.split_s;
+  }
+  if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bid, order, bi, bj)) return;
   const int i0 = bi * BM, j0 = bj * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
@@ -230,6 +235,11 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
     if (BLAY == GPX_LAY_KC) ke = min(ke, j0 + BN); else kb = max(kb, j0);
   }
   kb &= ~(BK - 1);
+  if (g.split_s > 1) {   // this workgroup's slice of K (a multiple of BK; plain operands only)
+    const int ks = ((g.K + g.split_s * BK - 1) / (g.split_s * BK)) * BK;
+    kb = part * ks;
+    ke = min(g.K, kb + ks);
+  }
 
   v4d acc[TM][TN];
 #pragma unroll
@@ -406,6 +416,17 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
   // epilogue: C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
   // Cin is read with clamped (always valid) addresses, 4 * TN loads in flight per step, so the
   // loads are branch-free and never serialise on their latency; stores are predicated.
+  if (g.split_s > 1) {   // raw accumulators of this K slice -> workspace tile (BM x BN, row-major)
+    double* wt = g.ws + (size_t)blockIdx.x * (BM * BN);
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int y = 0; y < TN; ++y)
+          wt[((wr * TM + x) * 16 + g4 + 4 * r) * BN + (wc * TN + y) * 16 + i16] = acc[x][y][r];
+    return;
+  }
   const double alpha = g.alpha, beta = g.beta;
   const bool use_c = beta != 0.0;
 #pragma unroll
@@ -454,6 +475,33 @@ bool tile_live(unsigned st, unsigned within, int tiles_m, int tiles_n, int lower
   return bi < tiles_m && bj < tiles_n && (!lower || bj <= bi);
 }
 
+// Sum of the split_s partial tiles of each tail tile (fixed order p = 0, 1, ...) and the GEMM epilogue
+// D = alpha * sum + beta * Cin (+ diag_add), one workgroup per tile (packed tile ids from tile0 on).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDesc g, int tiles_m, int tiles_n, unsigned tile0) {
+  int bi, bj;
+  if (!block_coords(tiles_m, tiles_n, g.c_lower, 0, tile0 + blockIdx.x, 0, bi, bj)) return;
+  const double* w0 = g.ws + (size_t)blockIdx.x * g.split_s * (BM * BN);
+  for (int e = threadIdx.x; e < BM * BN; e += 256) {
+    const int row = bi * BM + e / BN, col = bj * BN + e % BN;
+    if (row >= g.M || col >= g.N || (g.c_lower && col > row)) continue;
+    double v = 0.0;
+    for (int p = 0; p < g.split_s; ++p) v += w0[(size_t)p * (BM * BN) + e];
+    v *= g.alpha;
+    if (g.beta != 0.0) v += g.beta * g.Cin[(long)row * g.ldcin + col];
+    if (row == col) v += g.diag_add;
+    g.D[(long)row * g.ldd + col] = v;
+  }
+}
+
+thread_local double* t_ws = nullptr;
+thread_local size_t t_ws_elems = 0;
+
+long env_long(const char* name, long dflt) {
+  const char* e = getenv(name);
+  return e ? atol(e) : dflt;
+}
+
 constexpr unsigned TAIL_DYN_LDS = 32768;   // 64 KiB static + 32 KiB: two workgroups no longer fit in a CU's 160 KiB
 
 bool tail_split_enabled() {
@@ -480,7 +528,13 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
   // super-tile mapping: one block per tile, so the dispatcher spreads them over all XCDs and CUs
   // instead of packing the few live blocks of a sparse grid onto a handful of CUs.
   const long ntiles = g.c_lower ? (long)max(tm, tn) * (max(tm, tn) + 1) / 2 : (long)tm * tn;
-  if (ntiles <= 512) {
+  // Mid-size LOWER launches too: the triangular grid of 8 x 8 super-tiles deals the XCDs unequal
+  // numbers of live tiles (32 x 32 tiles: 100 on two XCDs, 36 on two others -> two rounds for one
+  // round of work); packed row-major ids go round-robin over the XCDs -- every XCD then holds every
+  // 8th tile of a few rows, the same 8 + 8 panels per 64 tiles as a super-tile once rows are 64 wide.
+  static const long packed_max = env_long("GPX_GEMM_PACKED_MAX", 4096);   // development override
+  const bool packed = ntiles <= 512 || (g.c_lower && TM * TN >= 16 && ntiles <= packed_max);
+  if (packed) {
     nsuper = 0;
     grid = dim3((unsigned)ntiles);
   }
@@ -491,7 +545,14 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     if (g.b_tri) order = g.b_lay == GPX_LAY_RC ? ORD_COLS_ASC : ORD_COLS_DESC;      // k >= j0  |  k < j0 + BN
     else if (g.a_tri && g.a_lay == GPX_LAY_KC) order = ORD_ROWS_DESC;               // k < i0 + BM
   }
+  static const bool log_shapes = getenv("GPX_GEMM_LOG") != nullptr;   // development: one line per kernel launch
+  auto log_launch = [&](const char* part, unsigned blocks) {
+    if (log_shapes)
+      fprintf(stderr, "GEMMLOG %d %d %d lower=%d atri=%d btri=%d inplace=%d cfg=%d part=%s blocks=%u\n", g.M, g.N, g.K,
+              g.c_lower, g.a_tri, g.b_tri, g.inplace, TM * 10 + TN, part, blocks);
+  };
   auto launch = [&](dim3 gr, unsigned dyn, unsigned bid0) {
+    log_launch(dyn ? "tail" : "main", gr.x);
     if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
       hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
     else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
@@ -523,7 +584,41 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     }
     if (live == rem) main_ids = chunk * 512;
   }
-  if (main_ids == grid.x) {
+  if (packed && ntiles > 512 && rem > 0 && rem <= 256 && tail_split_enabled()) {
+    // packed ids: the tail is simply the last `rem` tiles.  Few of them and a long K: split K over
+    // several workgroups per tile (one workgroup per CU, all CUs busy, each at full MFMA rate), partial
+    // tiles into the workspace, summed in a fixed order.  Otherwise one workgroup per CU as below.
+    static const long splitk_on = env_long("GPX_GEMM_SPLITK", 1);   // development switch
+    const unsigned main_tiles = (unsigned)(ntiles - rem);
+    launch(dim3(main_tiles), 0, 0);
+    int split = 0;
+    if (splitk_on && t_ws != nullptr && rem <= 128 && g.K >= 1024 && !g.a_tri && !g.b_tri && !g.inplace) {
+      split = (int)(256 / rem);
+      while (split > 1 && g.K / split < 128) --split;
+      if ((size_t)rem * split * (BM * BN) > t_ws_elems) split = (int)(t_ws_elems / ((size_t)rem * BM * BN));
+    }
+    if (split > 1) {
+      GemmDesc gs = g;
+      gs.split_s = split;
+      gs.split_tile0 = main_tiles;
+      gs.ws = t_ws;
+      auto launch_split = [&](dim3 gr) {
+        log_launch("split", gr.x);
+        if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
+          hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), gr, block, TAIL_DYN_LDS, s, gs, tm, tn, nsuper, 0u, order);
+        else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
+          hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC, TM, TN>), gr, block, TAIL_DYN_LDS, s, gs, tm, tn, nsuper, 0u, order);
+        else if (g.a_lay == GPX_LAY_RC && g.b_lay == GPX_LAY_RC)
+          hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC, TM, TN>), gr, block, TAIL_DYN_LDS, s, gs, tm, tn, nsuper, 0u, order);
+        else
+          hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), gr, block, TAIL_DYN_LDS, s, gs, tm, tn, nsuper, 0u, order);
+      };
+      launch_split(dim3((unsigned)(rem * split)));
+      hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3((unsigned)rem), dim3(256), 0, s, gs, tm, tn, main_tiles);
+    } else {
+      launch(dim3((unsigned)rem), TAIL_DYN_LDS, main_tiles);
+    }
+  } else if (main_ids == grid.x) {
     launch(grid, 0, 0);
   } else {
     launch(dim3(main_ids), 0, 0);
@@ -534,6 +629,11 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
 }
 
 }  // namespace
+
+void gpx_gemm_set_workspace(double* ws, size_t elems) {
+  t_ws = ws;
+  t_ws_elems = elems;
+}
 
 int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   if (g.M <= 0 || g.N <= 0) return 0;
@@ -549,10 +649,6 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   // 128 x 128 tiles unless that leaves most of the 256 CUs (2 workgroups each) idle.  In-place
   // launches (D aliases an operand) rely on one workgroup owning a whole operand panel: 128 only.
   const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.c_lower ? 2 : 1);
-  static const bool log_shapes = getenv("GPX_GEMM_LOG") != nullptr;   // development: one line per launch
-  if (log_shapes)
-    fprintf(stderr, "GEMMLOG %d %d %d lower=%d atri=%d btri=%d inplace=%d cfg=%d\n", g.M, g.N, g.K, g.c_lower,
-            g.a_tri, g.b_tri, g.inplace, (g.inplace == GPX_INPLACE_A && g.M <= 16384) ? 1 : (g.inplace == GPX_INPLACE_B && g.N <= 16384) ? 41 : (g.inplace || big_tiles >= 384) ? 4 : 2);
   // In-place right-multiplies (D aliases A, N <= 128) with few rows: 32-row tiles, still 128 wide, so
   // that a 128 x 128 x 128 leaf solve is spread over 4 CUs instead of being one CU's 13.7 us of MFMA
   // time.  (When D aliases B the workgroup must own all K = M <= 128 rows: 128-row tiles only.)

@@ -110,6 +110,9 @@ int trsm_ltn(hipStream_t s, int n, int m, const double* L, long ldl, const doubl
 // leaf (factor + inverse of the 128 x 128 diagonal block), one in-place GEMM for the panel below it,
 // one lower rank-128 update of the rest -- 3 dependent launches per panel where the recursion needs
 // ~8 (its solves and updates split further); the block is latency-bound, not flop-bound.
+// (A one-panel look-ahead on a second stream -- next leaf + solve under the rest of the update -- was
+// measured and lost: potrf(4096) 2.33 -> 2.74 ms, the two cross-stream event waits per panel cost
+// more than the 37 us leaf they hide.)
 int potrf_panels(hipStream_t s, int n, double* A, long lda, double* dinv, int* info_dev, int off) {
   for (int j0 = 0; j0 < n; j0 += NB) {
     const int jb = n - j0 < NB ? n - j0 : NB;
@@ -207,7 +210,13 @@ int fetch_info(gpx_handle* h, int* info) {
 
 struct DeviceGuard {
   int prev = -1;
-  explicit DeviceGuard(int dev) {
+  explicit DeviceGuard(int dev) { enter(dev); }
+  // an entry point working for handle h: its device current, its split-K workspace the thread's
+  explicit DeviceGuard(const gpx_handle* h) {
+    enter(h->device);
+    gpx_gemm_set_workspace(h->gemm_ws, h->gemm_ws ? GPX_GEMM_WS_ELEMS : 0);
+  }
+  void enter(int dev) {
     (void)hipGetDevice(&prev);
     if (prev != dev) (void)hipSetDevice(dev);
     else prev = -1;
@@ -261,6 +270,7 @@ int gpx_create(gpx_handle** out, int device) {
   h->device = device;
   if (hipMalloc(&h->red, GPX_RED_ELEMS * sizeof(double)) != hipSuccess ||
       hipMalloc(&h->info_dev, 256) != hipSuccess ||
+      hipMalloc(&h->gemm_ws, GPX_GEMM_WS_ELEMS * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&h->host_pin, GPX_HOST_PIN * sizeof(double)) != hipSuccess) {
     gpx_set_error("gpx_create: allocation failed");
     gpx_destroy(h);
@@ -272,9 +282,10 @@ int gpx_create(gpx_handle** out, int device) {
 
 int gpx_destroy(gpx_handle* h) {
   if (!h) return 0;
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   if (h->red) (void)hipFree(h->red);
   if (h->info_dev) (void)hipFree(h->info_dev);
+  if (h->gemm_ws) (void)hipFree(h->gemm_ws);
   if (h->host_pin) (void)hipHostFree(h->host_pin);
   delete h;
   return 0;
@@ -288,7 +299,7 @@ int gpx_set_stream(gpx_handle* h, void* stream) {
 
 int gpx_synchronize(gpx_handle* h) {
   GPX_REQUIRE(h != nullptr, "null handle");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   GPX_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -306,7 +317,7 @@ int gpx_gram(gpx_handle* h, int kind, const double* X1, int n1, int ldx1, const 
   GPX_REQUIRE(X1 != nullptr && ldx1 >= d && ldx2 >= d, "gram: bad X");
   GPX_TRY(check_mat("gram: K", K, ldk, n2));
   GPX_REQUIRE(uplo == GPX_FULL || (uplo == GPX_LOWER && n1 == n2), "gram: GPX_LOWER needs a square matrix");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_gram_launch(h->stream, X1, n1, ldx1, X2, n2, ldx2, d, sigma, b, diag_add, K, ldk, uplo);
 }
 
@@ -323,7 +334,7 @@ int gpx_gram_dtheta(gpx_handle* h, int kind, const double* X1, int n1, int ldx1,
   GPX_REQUIRE(ld >= n2 && ldx1 >= d && ldx2 >= d, "gram_dtheta: bad leading dimension");
   GPX_REQUIRE(n1 <= 65535, "gram_dtheta: n1 too large for the dense dtheta path");
   GPX_REQUIRE(nbeta == 1 || plane >= (size_t)(n1 - 1) * ld + n2, "gram_dtheta: plane stride too small");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_gram_dtheta_launch(h->stream, X1, n1, ldx1, X2, n2, ldx2, d, nbeta, sigma, b, K, dsigma,
                                 dbeta, ld, plane);
 }
@@ -334,7 +345,7 @@ int gpx_potrf(gpx_handle* h, int n, double* A, int lda, double* dinv) {
   if (n == 0) return 0;
   GPX_TRY(check_mat("potrf: A", A, lda, n));
   GPX_REQUIRE(dinv != nullptr && gpx_aligned16(dinv), "potrf: dinv null or misaligned");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), h->stream));
   GPX_TRY(potrf_rec(h->stream, n, A, lda, dinv, h->info_dev, 0));
   int info = 0;
@@ -348,7 +359,7 @@ int gpx_potrf_async(gpx_handle* h, int n, double* A, int lda, double* dinv, int*
   if (n == 0) return 0;
   GPX_TRY(check_mat("potrf_async: A", A, lda, n));
   GPX_REQUIRE(dinv != nullptr && gpx_aligned16(dinv) && info_dev != nullptr, "potrf_async: dinv/info null or misaligned");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return potrf_rec(h->stream, n, A, lda, dinv, info_dev, info_offset);
 }
 
@@ -359,7 +370,7 @@ int gpx_trsm_right(gpx_handle* h, int m, int n, const double* L, int ldl, const 
   GPX_TRY(check_mat("trsm_right: L", L, ldl, n));
   GPX_TRY(check_mat("trsm_right: X", X, ldx, n));
   GPX_REQUIRE(dinv != nullptr && gpx_aligned16(dinv), "trsm_right: dinv null or misaligned");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return trsm_rlt(h->stream, m, n, L, ldl, dinv, X, ldx);
 }
 
@@ -368,7 +379,7 @@ int gpx_diag_inv(gpx_handle* h, int n, const double* L, int ldl, double* dinv) {
   if (n <= 0) return 0;
   GPX_TRY(check_mat("diag_inv: L", L, ldl, n));
   GPX_REQUIRE(dinv != nullptr, "diag_inv: null dinv");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_leaf_diag_inv_batched(h->stream, n, L, ldl, dinv);
 }
 
@@ -379,14 +390,14 @@ int gpx_trsm(gpx_handle* h, int trans, int n, int nrhs, const double* L, int ldl
   GPX_TRY(check_mat("trsm: L", L, ldl, n));
   GPX_TRY(check_mat("trsm: B", B, ldb, nrhs));
   GPX_REQUIRE(dinv != nullptr && gpx_aligned16(dinv), "trsm: dinv null or misaligned");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return solve_lower(h, trans, n, nrhs, L, ldl, dinv, B, ldb);
 }
 
 int gpx_logdet(gpx_handle* h, int n, const double* L, int ldl, double* out_host) {
   GPX_REQUIRE(h != nullptr && out_host != nullptr, "logdet: null argument");
   if (n <= 0) { *out_host = 0.0; return 0; }
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   double* sc = red_scalars(h);
   GPX_TRY(gpx_logdet_launch(h->stream, n, L, ldl, h->red, sc));
   return fetch(h, sc, out_host, 1);
@@ -395,7 +406,7 @@ int gpx_logdet(gpx_handle* h, int n, const double* L, int ldl, double* out_host)
 int gpx_dot(gpx_handle* h, int n, const double* x, const double* y, double* out_host) {
   GPX_REQUIRE(h != nullptr && out_host != nullptr, "dot: null argument");
   if (n <= 0) { *out_host = 0.0; return 0; }
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   double* sc = red_scalars(h);
   GPX_TRY(gpx_dot_launch(h->stream, n, x, y, h->red, sc));
   return fetch(h, sc, out_host, 1);
@@ -406,7 +417,7 @@ int gpx_trtri(gpx_handle* h, int n, double* L, int ldl, const double* dinv, doub
   if (n <= 0) return 0;
   GPX_TRY(check_mat("trtri: L", L, ldl, n));
   GPX_REQUIRE(dinv != nullptr && work != nullptr && gpx_aligned16(work), "trtri: null/misaligned workspace");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return trtri_rec(h->stream, n, L, ldl, dinv, work);
 }
 
@@ -416,7 +427,7 @@ int gpx_lauum(gpx_handle* h, int n, const double* W, int ldw, double* Kinv, int 
   GPX_TRY(check_mat("lauum: W", W, ldw, n));
   GPX_TRY(check_mat("lauum: Kinv", Kinv, ldk, n));
   GPX_REQUIRE(W != Kinv, "lauum: out of place only");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   // Kinv = W^T W: op(A) = W^T stored as W [k][i] (RC, lower), op(B) = W stored [k][j] (RC, lower)
   GemmDesc g = mk(W, ldw, GPX_LAY_RC, W, ldw, GPX_LAY_RC, nullptr, 0, Kinv, ldk, n, n, n, 1.0, 0.0);
   g.a_tri = 1;
@@ -431,7 +442,7 @@ int gpx_syrk_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double* 
   if (m <= 0) return 0;
   GPX_TRY(check_mat("syrk_sub: C", C, ldc, m));
   if (n > 0) GPX_TRY(check_mat("syrk_sub: V", V, ldv, m));
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   GemmDesc g = mk(V, ldv, GPX_LAY_RC, V, ldv, GPX_LAY_RC, C, ldc, C, ldc, m, m, n < 0 ? 0 : n, -1.0, 1.0);
   g.c_lower = (uplo == GPX_LOWER);
   g.diag_add = diag_add;
@@ -442,7 +453,7 @@ int gpx_syrk_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double* 
 int gpx_gemm(gpx_handle* h, int transa, int transb, int M, int N, int K, double alpha,
              const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc) {
   GPX_REQUIRE(h != nullptr, "null handle");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   // row-major: A stored M x K (transa=0, k contiguous -> KC) or K x M (transa=1 -> RC);
   //            B stored K x N (transb=0 -> RC) or N x K (transb=1 -> KC).
   GemmDesc g = mk(A, lda, transa ? GPX_LAY_RC : GPX_LAY_KC, B, ldb, transb ? GPX_LAY_KC : GPX_LAY_RC, C,
@@ -454,7 +465,7 @@ int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, c
              double* y) {
   GPX_REQUIRE(h != nullptr && A && x && y, "gemv: null argument");
   GPX_REQUIRE(lda >= m, "gemv: lda too small");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_gemv_launch(h->stream, trans, n, m, A, lda, x, y, h->red, RED_USABLE);
 }
 
@@ -467,7 +478,7 @@ int gpx_gemv_static(gpx_handle* h, int trans, int n, int m, const double* A, int
               GPX_STATIC_SCRATCH_ELEMS);
   double* sc = gpx_static_scratch(h->device);
   GPX_REQUIRE(sc != nullptr, "gemv_static: static scratch of device %d was not initialised", h->device);
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   // the partial kernel overwrites every slot the final kernel reads, so the previous call's contents
   // of the shared array need no clearing
   return gpx_gemv_launch(h->stream, trans, n, m, A, lda, x, y, sc, GPX_STATIC_SCRATCH_ELEMS);
@@ -476,19 +487,19 @@ int gpx_gemv_static(gpx_handle* h, int trans, int n, int m, const double* A, int
 int gpx_colsumsq_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double base, double* var) {
   GPX_REQUIRE(h != nullptr && V && var, "colsumsq_sub: null argument");
   GPX_REQUIRE(n >= 0 && m >= 0 && ldv >= m, "colsumsq_sub: bad shape (n %d, m %d, ldv %d)", n, m, ldv);
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_colsumsq_sub_launch(h->stream, n, m, V, ldv, base, var, h->red, RED_USABLE);
 }
 
 int gpx_symmetrize(gpx_handle* h, int n, double* A, int lda) {
   GPX_REQUIRE(h != nullptr && A, "symmetrize: null argument");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_symmetrize_launch(h->stream, n, A, lda);
 }
 
 int gpx_diag(gpx_handle* h, int n, const double* A, int lda, double* diag_out) {
   GPX_REQUIRE(h != nullptr && A && diag_out, "diag: null argument");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_diag_launch(h->stream, n, A, lda, diag_out);
 }
 
@@ -510,7 +521,7 @@ int gpx_grad_trace(gpx_handle* h, int kind, const double* X, int n, int ldx, int
   GPX_REQUIRE(n > 0 && X && alpha && ldx >= d, "grad_trace: bad arguments");
   GPX_TRY(check_mat("grad_trace: Kinv", Kinv, ldk, n));
   for (int k = 0; k < nbeta; ++k) GPX_REQUIRE(b.b[k] > 0.0, "grad_trace: beta[%d] must be positive", k);
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   double* sc = red_scalars(h);
   GPX_TRY(gpx_grad_trace_launch(h->stream, X, ldx, d, nbeta, sigma, b, alpha, Kinv, ldk, 0, 0, n, n, h->red,
                                 RED_USABLE, sc));
@@ -533,7 +544,7 @@ int gpx_grad_trace_slab(gpx_handle* h, int kind, const double* X, int n, int ldx
               row_off, nrows, col_off, ncols, n, n);
   GPX_TRY(check_mat("grad_trace_slab: Kinv", Kinv_slab, ldk, ncols));
   for (int k = 0; k < nbeta; ++k) GPX_REQUIRE(b.b[k] > 0.0, "grad_trace_slab: beta[%d] must be positive", k);
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   double* sc = red_scalars(h);
   GPX_TRY(gpx_grad_trace_launch(h->stream, X, ldx, d, nbeta, sigma, b, alpha, Kinv_slab, ldk, row_off, col_off,
                                 nrows, ncols, h->red, RED_USABLE, sc));
@@ -558,7 +569,7 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
     for (int k = 0; k < nbeta; ++k) GPX_REQUIRE(b.b[k] > 0.0, "gpr_lml_grad: beta[%d] must be positive", k);
     GPX_REQUIRE((size_t)n * ldk >= gpx_trtri_work_elems(n), "gpr_lml_grad: Kinv too small for trtri scratch");
   }
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   hipStream_t s = h->stream;
   // Ky = K + noise I (lower), regression.py:47-48,58-59
   GPX_TRY(gpx_gram_launch(s, X, n, ldx, X, n, ldx, d, sigma, b, noise, Ky, ldk, GPX_LOWER));
@@ -622,7 +633,7 @@ int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, in
   GPX_REQUIRE(gpx_aligned16(vec) && dinv && gpx_aligned16(dinv), "gpr_predict: scratch must be 16-byte aligned");
   if (full_cov) GPX_TRY(check_mat("gpr_predict: cov", cov, ldc, m));
   else GPX_REQUIRE(var != nullptr, "gpr_predict: var is null");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   hipStream_t s = h->stream;
   // a = L^-1 y  (regression.py:37)
   double* rhs = vec;
@@ -667,7 +678,7 @@ int gpx_gpr_predict_inv(gpx_handle* h, int kind, const double* X, int n, int ldx
   GPX_REQUIRE(Ks != V, "gpr_predict_inv: Ks and V must be distinct buffers");
   if (full_cov) GPX_TRY(check_mat("gpr_predict_inv: cov", cov, ldc, m));
   else GPX_REQUIRE(var != nullptr, "gpr_predict_inv: var is null");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   hipStream_t s = h->stream;
   // k* = K(Xtr, Xs) (regression.py:33); V = L^-1 k* (regression.py:38) as a triangular multiply by W
   GPX_TRY(gpx_gram_launch(s, X, n, ldx, Xs, m, ldxs, d, sigma, b, 0.0, Ks, ldv, GPX_FULL));
@@ -695,7 +706,7 @@ int gpx_ep_scale(gpx_handle* h, int n, const double* K, int ldk, const double* s
   GPX_REQUIRE(h != nullptr && K && sv && B && SK, "ep_scale: null argument");
   GPX_REQUIRE(n <= 65535, "ep_scale: n too large");
   GPX_REQUIRE(ldk >= n && ldb >= n && ldsk >= n, "ep_scale: bad leading dimension");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_ep_scale_launch(h->stream, n, K, ldk, sv, B, ldb, SK, ldsk);
 }
 
@@ -708,7 +719,7 @@ int gpx_ep_recompute(gpx_handle* h, int n, const double* K, int ldk, const doubl
   GPX_TRY(check_mat("ep_recompute: B", Bbuf, ld, n));
   GPX_TRY(check_mat("ep_recompute: V", Vbuf, ld, n));
   GPX_TRY(check_mat("ep_recompute: Sigma", Sigma, ld, n));
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   hipStream_t s = h->stream;
   GPX_TRY(gpx_sqrt_launch(s, n, tau, svec));                                   // S = sqrt(tau)
   GPX_TRY(gpx_ep_scale_launch(s, n, K, ldk, svec, Bbuf, ld, Vbuf, ld));        // B, S K
@@ -734,7 +745,7 @@ int gpx_trmm(gpx_handle* h, int n, int m, const double* L, int ldl, const double
   GPX_TRY(check_mat("trmm: B", B, ldb, m));
   GPX_TRY(check_mat("trmm: Out", Out, ldo, m));
   GPX_REQUIRE(Out != B, "trmm: Out must not alias B");
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   // op(A) = L (stored [i][k], valid k <= i), op(B) = B stored [k][j]
   GemmDesc g = mk(L, ldl, GPX_LAY_KC, B, ldb, GPX_LAY_RC, nullptr, 0, Out, ldo, n, m, n, 1.0, 0.0);
   g.a_tri = 1;
@@ -748,7 +759,7 @@ int gpx_ep_sweep(gpx_handle* h, int n, double* Sigma, int ld, const double* y, d
   GPX_TRY(check_mat("ep_sweep: Sigma", Sigma, ld, n));
   GPX_REQUIRE(gpx_aligned16(work), "ep_sweep: work must be 16-byte aligned");
   if (count == 0) return 0;
-  DeviceGuard dg(h->device);
+  DeviceGuard dg(h);
   return gpx_ep_sweep_launch(h->stream, n, Sigma, ld, y, tau, nu, order_host, count, work);
 }
 

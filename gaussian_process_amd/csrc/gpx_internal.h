@@ -15,6 +15,7 @@ struct gpx_handle {
   double* red = nullptr;      // device, RED_ELEMS doubles
   int* info_dev = nullptr;    // device int
   double* host_pin = nullptr; // pinned host staging for scalars, HOST_PIN doubles
+  double* gemm_ws = nullptr;  // device, GPX_GEMM_WS_ELEMS doubles: partial tiles of the GEMM's split-K tail
 };
 
 constexpr size_t GPX_RED_ELEMS = 1u << 23;  // 64 MiB of reduction partials
@@ -61,7 +62,18 @@ struct GemmDesc {
   double diag_add;   // added to D[i][i]
   int inplace;       // GPX_INPLACE_A: D aliases A (N <= 128, row tiles independent); GPX_INPLACE_B: D aliases B
                      // (M <= 128, column tiles independent); one workgroup owns the whole operand panel
+  // split-K tail (filled by gpx_gemm_launch, not by callers): the last tiles of a multi-round launch are
+  // computed by split_s workgroups each over a slice of K, raw accumulators into ws, then summed in a
+  // fixed order by a small kernel (see launch_cfg)
+  int split_s = 0;
+  unsigned split_tile0 = 0;
+  double* ws = nullptr;
 };
+
+// Workspace of the split-K tail for the calling thread's current handle (set by the C ABI entry points,
+// gpx_api.hip); nullptr = no split-K.
+void gpx_gemm_set_workspace(double* ws, size_t elems);
+constexpr size_t GPX_GEMM_WS_ELEMS = (size_t)256 * 128 * 128;   // 256 workgroups x one 128 x 128 tile: 32 MiB
 
 int gpx_gemm_launch(hipStream_t s, const GemmDesc& g);
 

@@ -370,3 +370,24 @@ print(" ".join(repr(v) for v in out))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.array([float(v) for v in r.stdout.strip().splitlines()[-1].split()]))
     assert np.abs(outs[0] - outs[1]).max() <= 1e-12 * np.abs(outs[0]).max()
+
+
+@pytest.mark.parametrize("m,k,lower", [(4096, 1024, 1), (4200, 1100, 1), (4096, 2048, 0), (5000, 1500, 1)])
+def test_gemm_mid_size_lower_launches_packed_ids_and_split_k_tail(rt, m, k, lower):
+    """Lower launches of 513..4096 tiles use packed tile ids; a short last round (<= 128 tiles) with a long
+    K is computed split over K into the handle's workspace and summed in a fixed order (gemm_f64.hip,
+    launch_cfg).  C - V^T V + diag against NumPy; twice, the results must be bitwise equal."""
+    rng = np.random.default_rng(m + k)
+    V = rng.standard_normal((k, m))
+    C0 = rng.standard_normal((m, m))
+    ref = C0 - V.T @ V + 0.3 * np.eye(m)
+    if lower:
+        ref = np.tril(ref) + np.triu(C0, 1)
+    dV = up(rt, V)
+    outs = []
+    for _ in range(2):
+        dC = up(rt, C0)
+        ok(rt.lib.gpx_syrk_sub(rt.h, k, m, P(dV), dV.shape[1], P(dC), dC.shape[1], 0.3, 1 if lower else 0))
+        outs.append(down(rt, dC, m, m))
+    assert relerr(outs[0], ref) < 1e-13
+    assert np.array_equal(outs[0], outs[1])

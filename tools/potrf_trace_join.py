@@ -24,7 +24,7 @@ for r, s, ph in zip(gem, shapes, phase_of):
     fl = 2.0 * M * N * K * (0.5 if lower else 1.0) * (0.5 if (atri or btri) else 1.0)
     t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
     key = "K<=128" if K <= 128 else "K<=512" if K <= 512 else "K<=2048" if K <= 2048 else "K<=8192" if K <= 8192 else "K>8192"
-    key = ph + " " + key + " " + s[8]
+    key = ph + " " + key + " " + s[8] + (" " + s[9] if len(s) > 9 and not s[9].endswith("main") else "")
     c = cls.setdefault(key, [0, 0.0, 0.0])
     c[0] += 1; c[1] += t; c[2] += fl
     tot_t += t; tot_f += fl
@@ -34,3 +34,11 @@ for k in sorted(cls):
 lt = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in leaf) * 1e-9
 span = (int(rows[-1]["End_Timestamp"]) - int(rows[gi + 1]["Start_Timestamp"])) * 1e-9
 print("gemm total %.1f ms (%.2f TF avg), leaves %.1f ms, span %.1f ms -> gaps/other %.1f ms" % (tot_t * 1e3, tot_f / tot_t / 1e12, lt * 1e3, span * 1e3, (span - tot_t - lt) * 1e3))
+# the long launches one by one
+print("launches with K >= 1024 in potrf:")
+for r, s, ph in zip(gem, shapes, phase_of):
+    M, N, K = int(s[1]), int(s[2]), int(s[3])
+    if ph == "potrf" and K >= 1024:
+        lower = int(s[4].split("=")[1])
+        t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+        print("  %5d %5d %5d %s  %9.1f us  %6.1f TF" % (M, N, K, " ".join(s[4:]), t, 2.0 * M * N * K * (0.5 if lower else 1.0) / t / 1e6))
