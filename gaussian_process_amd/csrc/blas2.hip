@@ -50,17 +50,17 @@ __global__ __launch_bounds__(256) void gemvT_partial_kernel(int n, int m, const 
   partials[(size_t)blockIdx.y * m + j] = acc;
 }
 __global__ __launch_bounds__(256) void gemvT_final_kernel(int nchunks, int m, const double* partials,
-                                                           double* y) {
+                                                           double alpha, double beta, double* y) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
   double acc = 0.0;
   for (int c = 0; c < nchunks; ++c) acc += partials[(size_t)c * m + j];
-  y[j] = acc;
+  y[j] = beta != 0.0 ? fma(beta, y[j], alpha * acc) : alpha * acc;
 }
 
 // y[i] = sum_j A[i][j] x[j]: one wave per row.
 __global__ __launch_bounds__(256) void gemvN_kernel(int n, int m, const double* A, long lda,
-                                                    const double* x, double* y) {
+                                                    const double* x, double alpha, double beta, double* y) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void gemvN_kernel(int n, int m, const double* 
   for (int j = lane; j < m; j += 64) acc = fma(a[j], x[j], acc);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-  if (lane == 0) y[row] = acc;
+  if (lane == 0) y[row] = beta != 0.0 ? fma(beta, y[row], alpha * acc) : alpha * acc;
 }
 
 // var[j] = base - sum_i V[i][j]^2  (diagonal of regression.py:41-44 / expectation_propagation.py:118)
@@ -189,7 +189,7 @@ int gpx_dot_launch(hipStream_t s, int n, const double* x, const double* y, doubl
 }
 
 int gpx_gemv_launch(hipStream_t s, int trans, int n, int m, const double* A, long lda,
-                    const double* x, double* y, double* red, size_t red_elems) {
+                    const double* x, double* y, double* red, size_t red_elems, double alpha, double beta) {
   if (n <= 0 || m <= 0) return 0;
   if (trans) {
     const int rows = chunk_rows(n, m, red_elems);
@@ -200,9 +200,9 @@ int gpx_gemv_launch(hipStream_t s, int trans, int n, int m, const double* A, lon
     }
     dim3 grid((m + 255) / 256, nchunks);
     hipLaunchKernelGGL(gemvT_partial_kernel, grid, dim3(256), 0, s, n, m, A, lda, x, red, rows);
-    hipLaunchKernelGGL(gemvT_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nchunks, m, red, y);
+    hipLaunchKernelGGL(gemvT_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nchunks, m, red, alpha, beta, y);
   } else {
-    hipLaunchKernelGGL(gemvN_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, m, A, lda, x, y);
+    hipLaunchKernelGGL(gemvN_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, m, A, lda, x, alpha, beta, y);
   }
   GPX_HIP(hipGetLastError());
   return 0;

@@ -479,18 +479,33 @@ bool tile_live(unsigned st, unsigned within, int tiles_m, int tiles_n, int lower
 // D = alpha * sum + beta * Cin (+ diag_add), one workgroup per tile (packed tile ids from tile0 on).
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmDesc g, int tiles_m, int tiles_n, unsigned tile0) {
+  // 16 workgroups per tile, 4 elements per thread, the split_s loads of an element independent of each
+  // other (one workgroup per tile walked 1024 dependent load rounds: 240 us for 16 tiles)
+  constexpr int CHUNKS = 16, PER = BM * BN / CHUNKS / 256;
+  const unsigned tile = blockIdx.x / CHUNKS, chunk = blockIdx.x % CHUNKS;
   int bi, bj;
-  if (!block_coords(tiles_m, tiles_n, g.c_lower, 0, tile0 + blockIdx.x, 0, bi, bj)) return;
-  const double* w0 = g.ws + (size_t)blockIdx.x * g.split_s * (BM * BN);
-  for (int e = threadIdx.x; e < BM * BN; e += 256) {
-    const int row = bi * BM + e / BN, col = bj * BN + e % BN;
+  if (!block_coords(tiles_m, tiles_n, g.c_lower, 0, tile0 + tile, 0, bi, bj)) return;
+  const double* w0 = g.ws + (size_t)tile * g.split_s * (BM * BN);
+  double v[PER];
+  int e[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    e[i] = (int)chunk * (BM * BN / CHUNKS) + i * 256 + threadIdx.x;
+    v[i] = 0.0;
+  }
+#pragma unroll 4
+  for (int p = 0; p < g.split_s; ++p) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] += w0[(size_t)p * (BM * BN) + e[i]];
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int row = bi * BM + e[i] / BN, col = bj * BN + e[i] % BN;
     if (row >= g.M || col >= g.N || (g.c_lower && col > row)) continue;
-    double v = 0.0;
-    for (int p = 0; p < g.split_s; ++p) v += w0[(size_t)p * (BM * BN) + e];
-    v *= g.alpha;
-    if (g.beta != 0.0) v += g.beta * g.Cin[(long)row * g.ldcin + col];
-    if (row == col) v += g.diag_add;
-    g.D[(long)row * g.ldd + col] = v;
+    double r = v[i] * g.alpha;
+    if (g.beta != 0.0) r += g.beta * g.Cin[(long)row * g.ldcin + col];
+    if (row == col) r += g.diag_add;
+    g.D[(long)row * g.ldd + col] = r;
   }
 }
 
@@ -614,7 +629,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
           hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), gr, block, TAIL_DYN_LDS, s, gs, tm, tn, nsuper, 0u, order);
       };
       launch_split(dim3((unsigned)(rem * split)));
-      hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3((unsigned)rem), dim3(256), 0, s, gs, tm, tn, main_tiles);
+      hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3((unsigned)rem * 16), dim3(256), 0, s, gs, tm, tn, main_tiles);
     } else {
       launch(dim3((unsigned)rem), TAIL_DYN_LDS, main_tiles);
     }

@@ -388,7 +388,11 @@ int gpx_trsm(gpx_handle* h, int trans, int n, int nrhs, const double* L, int ldl
   GPX_REQUIRE(h != nullptr, "null handle");
   if (n <= 0 || nrhs <= 0) return 0;
   GPX_TRY(check_mat("trsm: L", L, ldl, n));
-  GPX_TRY(check_mat("trsm: B", B, ldb, nrhs));
+  if (nrhs == 1) {   // one right-hand side: a strided vector (the TRSV kernels use scalar accesses)
+    GPX_REQUIRE(B != nullptr && ldb >= 1, "trsm: bad right-hand side vector");
+  } else {
+    GPX_TRY(check_mat("trsm: B", B, ldb, nrhs));
+  }
   GPX_REQUIRE(dinv != nullptr && gpx_aligned16(dinv), "trsm: dinv null or misaligned");
   DeviceGuard dg(h);
   return solve_lower(h, trans, n, nrhs, L, ldl, dinv, B, ldb);
@@ -467,6 +471,15 @@ int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, c
   GPX_REQUIRE(lda >= m, "gemv: lda too small");
   DeviceGuard dg(h);
   return gpx_gemv_launch(h->stream, trans, n, m, A, lda, x, y, h->red, RED_USABLE);
+}
+
+int gpx_gemv_acc(gpx_handle* h, int trans, int n, int m, double alpha, const double* A, int lda,
+                 const double* x, double beta, double* y) {
+  GPX_REQUIRE(h != nullptr && A && x && y, "gemv_acc: null argument");
+  GPX_REQUIRE(lda >= m, "gemv_acc: lda too small");
+  GPX_REQUIRE(x != y, "gemv_acc: x and y must not alias");
+  DeviceGuard dg(h);
+  return gpx_gemv_launch(h->stream, trans, n, m, A, lda, x, y, h->red, RED_USABLE, alpha, beta);
 }
 
 int gpx_gemv_static(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,

@@ -112,7 +112,8 @@ double* gpx_static_scratch(int device);    // device address of this GPU's copy 
 int gpx_logdet_launch(hipStream_t s, int n, const double* L, long ldl, double* red, double* out_dev);
 int gpx_dot_launch(hipStream_t s, int n, const double* x, const double* y, double* red, double* out_dev);
 int gpx_gemv_launch(hipStream_t s, int trans, int n, int m, const double* A, long lda,
-                    const double* x, double* y, double* red, size_t red_elems);
+                    const double* x, double* y, double* red, size_t red_elems, double alpha = 1.0,
+                    double beta = 0.0);   // y = alpha op(A) x + beta y
 int gpx_symmetrize_launch(hipStream_t s, int n, double* A, long lda);
 int gpx_diag_launch(hipStream_t s, int n, const double* A, long lda, double* out);
 int gpx_ep_scale_launch(hipStream_t s, int n, const double* K, long ldk, const double* sv, double* B,

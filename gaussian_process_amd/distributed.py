@@ -111,6 +111,11 @@ class GpuOps:
         _lib.check(self.lib.gpx_gemv(self.h, 0, A.shape[0], A.shape[1], self._p(A), A.stride(0), self._p(x),
                                      self._p(y)), "gpx_gemv")
 
+    def gemv_acc(self, trans, alpha, A, x, beta, y):
+        """y = alpha * op(A) x + beta * y for contiguous vectors x, y."""
+        _lib.check(self.lib.gpx_gemv_acc(self.h, trans, A.shape[0], A.shape[1], float(alpha), self._p(A), A.stride(0),
+                                         self._p(x), float(beta), self._p(y)), "gpx_gemv_acc")
+
     def colsumsq(self, V, base, var):
         """var[j] = base - sum_i V[i][j]^2."""
         _lib.check(self.lib.gpx_colsumsq_sub(self.h, V.shape[0], V.shape[1], self._p(V), V.stride(0), float(base),
@@ -210,6 +215,7 @@ class DistributedGP:
         RCCL's stream, ordered after the kernels already enqueued on the current stream; wait() makes
         the current stream wait, not the host.  gloo with device tensors (rehearsals with several ranks
         on one GPU): staged through the host and completed before returning."""
+        assert t.is_contiguous()       # RCCL needs it; checked on every backend so the gloo tests cover it
         if self._staged(t):
             host = t.cpu()
             self.dist.broadcast(host, src=src, group=group)
@@ -221,6 +227,7 @@ class DistributedGP:
 
     def _reduce(self, t, dst, group):
         """Sum `t` over `group` into rank dst's `t` (the other ranks' buffers are scratch afterwards)."""
+        assert t.is_contiguous()
         if self._staged(t):
             host = t.cpu()
             self.dist.reduce(host, dst=dst, op=self.dist.ReduceOp.SUM, group=group)
@@ -244,14 +251,17 @@ class DistributedGP:
     def _all_gather(self, out, mine, group, async_op=False):
         """out (members x len(mine)) <- every member's `mine`, in group-rank order."""
         if self._staged(mine):
+            assert out.is_contiguous() and mine.is_contiguous()
             host = mine.cpu()
             parts = [self.torch.empty_like(host) for _ in range(out.shape[0])]
             self.dist.all_gather(parts, host, group=group)
             out.copy_(self.torch.stack(parts))
             return _Done()
         if self._gloo or not mine.is_cuda:
+            assert out.is_contiguous() and mine.is_contiguous()
             self.dist.all_gather([out[i] for i in range(out.shape[0])], mine, group=group)
             return _Done()
+        assert out.is_contiguous() and mine.is_contiguous()
         w = self.dist.all_gather_into_tensor(out.view(-1), mine, group=group, async_op=async_op)
         return w if async_op else _Done()
 
@@ -314,13 +324,14 @@ class DistributedGP:
         self.CB = ops.empty(max(nlc, 1) * nb, self.G * nb)
         self.rowstg = [ops.empty(max(nlr, 1) * nb * nb) for _ in range(2)]
         cmax = max([g.transposed_max(q, k) for k in range(g.T)] + [1])
-        self.tsend = ops.empty(cmax * nb * nb)
-        self.trecv = [ops.empty(self.P, cmax * nb * nb) for _ in range(2)]
+        # both double-buffered by panel parity; flat, so that the (P x count) view of any panel is contiguous
+        self.tsend = [ops.empty(cmax * nb * nb) for _ in range(2)]
+        self.trecv = [ops.empty(self.P * cmax * nb * nb) for _ in range(2)]
         self.dstg = [ops.empty(nb * nb + dper) for _ in range(2)]
         self._ws = {}
         self.resident_bytes = dict(matrix=8 * total,
                                    panels=8 * (self.RB.numel() + self.CB.numel() + 2 * self.rowstg[0].numel()
-                                               + self.tsend.numel() + 2 * self.trecv[0].numel()
+                                               + 2 * self.tsend[0].numel() + 2 * self.trecv[0].numel()
                                                + 2 * self.dstg[0].numel()),
                                    lower_over_world=8 * g.lower_elems() // self.world)
 
@@ -442,10 +453,11 @@ class DistributedGP:
             cm = out["cnt_max"]
             with self._forwarding():
                 h_row.wait()
+                send = self.tsend[k % 2]
                 if cnt > 0:
-                    self.tsend[: cnt * nb * nb].view(cnt, nb, nb).copy_(piece.view(ntiles, nb, nb)[t0::step][:cnt])
-                out["h_T"] = self._all_gather(self.trecv[k % 2][:, : cm * nb * nb], self.tsend[: cm * nb * nb],
-                                              self.col_group, async_op=True)
+                    send[: cnt * nb * nb].view(cnt, nb, nb).copy_(piece.view(ntiles, nb, nb)[t0::step][:cnt])
+                out["h_T"] = self._all_gather(self.trecv[k % 2][: P * cm * nb * nb].view(P, cm * nb * nb),
+                                              send[: cm * nb * nb], self.col_group, async_op=True)
         return out
 
     def _file_panel(self, k, h):
@@ -473,7 +485,8 @@ class DistributedGP:
                 continue
             first = g.local_rows(src, k + 1)[t0]                       # a tile index I with I mod Q == q
             if self.cc:
-                tiles = self.trecv[k % 2][src, : cnt * nb * nb].view(cnt, nb, nb)
+                cm = h["cnt_max"]
+                tiles = self.trecv[k % 2][: P * cm * nb * nb].view(P, cm * nb * nb)[src, : cnt * nb * nb].view(cnt, nb, nb)
             else:
                 tiles = h["piece"].view(-1, nb, nb)[t0::step][:cnt]
             CBt[first // Q:: stride][:cnt, :, cols].copy_(tiles)
@@ -515,9 +528,9 @@ class DistributedGP:
 
     def rhs_buffer(self, m, zero=True):
         """Right-hand-side / solution container of the solves: (local tile rows * nb) x ld, ld = m
-        rounded up to even.  Tile row k of B lives in rows [lrow(k), lrow(k) + h_k) of the DIAGONAL
+        rounded up to even (1 for a single right-hand side).  Tile row k of B lives in rows [lrow(k), lrow(k) + h_k) of the DIAGONAL
         OWNER of k; the other rows are the fan-in workspace (partial sums / received solution tiles)."""
-        ld = max(2, m + (m & 1))
+        ld = 1 if m == 1 else m + (m & 1)          # one right-hand side: a contiguous vector (GEMV updates)
         R = self._buffer("rhs%d" % ld, self.grid.nlr(self.p) * self.nb, ld)
         if zero:
             R.zero_()
@@ -525,7 +538,7 @@ class DistributedGP:
 
     def _solve_tile(self, trans, k, Rk, m):
         hk = self.grid.tile_h(k)
-        self.ops.trsm_left(trans, self.slabs[k][:hk, :hk], self.dinv[k], Rk[:, :1] if m == 1 else Rk)
+        self.ops.trsm_left(trans, self.slabs[k][:hk, :hk], self.dinv[k], Rk)
 
     def solve_forward(self, R, m, t0=0):
         """R <- L^-1 R (regression.py:37-38,50) on tile rows >= t0 (the right-hand side must be zero above
@@ -551,8 +564,11 @@ class DistributedGP:
                 if rows > 0:
                     I1 = g.first_at_or_after(k + 1, p, P)
                     start = nb if p == pk else 0
-                    ops.gemm(0, 0, rows, ld, hk, -1.0, self.slabs[k][start: start + rows, :hk], Xk, 1.0,
-                             R[g.lrow(I1): g.lrow(I1) + rows])
+                    Lk, tail = self.slabs[k][start: start + rows, :hk], R[g.lrow(I1): g.lrow(I1) + rows]
+                    if ld == 1:
+                        ops.gemv_acc(0, -1.0, Lk, Xk.view(-1), 1.0, tail.view(-1))
+                    else:
+                        ops.gemm(0, 0, rows, ld, hk, -1.0, Lk, Xk, 1.0, tail)
 
     def solve_backward(self, R, m, t0=0):
         """R <- L^-T R (the second half of cho_solve behind regression.py:61) on tile rows >= t0.
@@ -573,8 +589,11 @@ class DistributedGP:
                 if rows > 0:
                     I1 = g.first_at_or_after(k + 1, p, P)
                     start = nb if mine else 0
-                    ops.gemm(1, 0, hk, ld, rows, -1.0, self.slabs[k][start: start + rows, :hk],
-                             R[g.lrow(I1): g.lrow(I1) + rows], 1.0 if mine else 0.0, tgt)
+                    Lk, below = self.slabs[k][start: start + rows, :hk], R[g.lrow(I1): g.lrow(I1) + rows]
+                    if ld == 1:
+                        ops.gemv_acc(1, -1.0, Lk, below.view(-1), 1.0 if mine else 0.0, tgt.view(-1))
+                    else:
+                        ops.gemm(1, 0, hk, ld, rows, -1.0, Lk, below, 1.0 if mine else 0.0, tgt)
                 elif not mine:
                     tgt.zero_()
                 if self.cc:

@@ -93,7 +93,8 @@ int gpx_trsm_right(gpx_handle* h, int m, int n, const double* L, int ldl, const 
                    int ldx);
 /* Recompute dinv for a factor L that did not come from gpx_potrf. */
 int gpx_diag_inv(gpx_handle* h, int n, const double* L, int ldl, double* dinv);
-/* B <- L^-1 B (trans = 0) or L^-T B (trans = 1); B is n x nrhs row-major (nrhs may be 1).
+/* B <- L^-1 B (trans = 0) or L^-T B (trans = 1); B is n x nrhs row-major (nrhs may be 1, in which case
+ * ldb is the stride of the vector and may be any value >= 1).
  * Replaces solve_triangular at regression.py:37-38,50, the second half of cho_solve behind
  * regression.py:61, and np.linalg.solve(L, .) at expectation_propagation.py:63,92,107-108,117,136. */
 int gpx_trsm(gpx_handle* h, int trans, int n, int nrhs, const double* L, int ldl,
@@ -122,6 +123,11 @@ int gpx_trmm(gpx_handle* h, int n, int m, const double* L, int ldl, const double
  * regression.py:39 (mean = a . V), expectation_propagation.py:65,94,116. */
 int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,
              double* y);
+/* y = alpha * op(A) x + beta * y (same kernels and fixed summation order as gpx_gemv; x and y must not
+ * alias): the single-right-hand-side updates r -= L[I, k] x_k / r -= L[I, k]^T x_I of the multi-GPU
+ * triangular solves behind regression.py:50,61. */
+int gpx_gemv_acc(gpx_handle* h, int trans, int n, int m, double alpha, const double* A, int lda,
+                 const double* x, double beta, double* y);
 /* var[j] = base - sum_i V[i][j]^2 for V n x m: the diagonal of K** - V^T V + noise I (regression.py:41-44)
  * and of expectation_propagation.py:118 without the m x m matrix; fixed-order reduction.  The multi-GPU
  * path sums the per-rank results (base = 0 on all ranks but one). */

@@ -92,6 +92,14 @@ class NumpyOps:
         n, m = A.shape
         y.numpy()[:n] = A.numpy() @ x.numpy()[:m]
 
+    def gemv_acc(self, trans, alpha, A, x, beta, y):
+        a = A.numpy()
+        n, m = a.shape
+        if trans:
+            y.numpy()[:m] = alpha * (a.T @ x.numpy()[:n]) + (beta * y.numpy()[:m] if beta != 0.0 else 0.0)
+        else:
+            y.numpy()[:n] = alpha * (a @ x.numpy()[:m]) + (beta * y.numpy()[:n] if beta != 0.0 else 0.0)
+
     def colsumsq(self, V, base, var):
         m = V.shape[1]
         var.numpy()[:m] = base - (V.numpy() ** 2).sum(axis=0)
