@@ -526,11 +526,11 @@ class DistributedGP:
             buf = self._ws[name] = self.ops.empty(max(rows, 1), cols)
         return buf
 
-    def rhs_buffer(self, m, zero=True):
+    def rhs_buffer(self, m, zero=True, vector=False):
         """Right-hand-side / solution container of the solves: (local tile rows * nb) x ld, ld = m
-        rounded up to even (1 for a single right-hand side).  Tile row k of B lives in rows [lrow(k), lrow(k) + h_k) of the DIAGONAL
+        rounded up to even (vector=True: m = 1 and ld = 1).  Tile row k of B lives in rows [lrow(k), lrow(k) + h_k) of the DIAGONAL
         OWNER of k; the other rows are the fan-in workspace (partial sums / received solution tiles)."""
-        ld = 1 if m == 1 else m + (m & 1)          # one right-hand side: a contiguous vector (GEMV updates)
+        ld = 1 if vector else max(2, m + (m & 1))   # vector: ONE right-hand side held contiguously (GEMV updates)
         R = self._buffer("rhs%d" % ld, self.grid.nlr(self.p) * self.nb, ld)
         if zero:
             R.zero_()
@@ -538,7 +538,7 @@ class DistributedGP:
 
     def _solve_tile(self, trans, k, Rk, m):
         hk = self.grid.tile_h(k)
-        self.ops.trsm_left(trans, self.slabs[k][:hk, :hk], self.dinv[k], Rk)
+        self.ops.trsm_left(trans, self.slabs[k][:hk, :hk], self.dinv[k], Rk[:, :1] if m == 1 else Rk)
 
     def solve_forward(self, R, m, t0=0):
         """R <- L^-1 R (regression.py:37-38,50) on tile rows >= t0 (the right-hand side must be zero above
@@ -620,7 +620,7 @@ class DistributedGP:
         alpha (n doubles each) and the same LML."""
         g, ops, t, n, nb = self.grid, self.ops, self.torch, self.n, self.nb
         _lib.check(self.info_value, "distributed potrf")
-        R = self.rhs_buffer(1)
+        R = self.rhs_buffer(1, vector=True)
         for k in self._own_tiles():
             hk = g.tile_h(k)
             R[g.lrow(k): g.lrow(k) + hk, 0].copy_(self.y[k * nb: k * nb + hk])
