@@ -547,7 +547,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
   // numbers of live tiles (32 x 32 tiles: 100 on two XCDs, 36 on two others -> two rounds for one
   // round of work); packed row-major ids go round-robin over the XCDs -- every XCD then holds every
   // 8th tile of a few rows, the same 8 + 8 panels per 64 tiles as a super-tile once rows are 64 wide.
-  static const long packed_max = env_long("GPX_GEMM_PACKED_MAX", 4096);   // development override
+  static const long packed_max = env_long("GPX_GEMM_PACKED_MAX", 9000);   // development override
   const bool packed = ntiles <= 512 || (g.c_lower && TM * TN >= 16 && ntiles <= packed_max);
   if (packed) {
     nsuper = 0;
