@@ -661,6 +661,28 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   GPX_REQUIRE(g.ldb >= (g.b_lay == GPX_LAY_KC ? g.K : g.N), "gemm: ldb too small");
   GPX_REQUIRE(g.ldd >= g.N, "gemm: ldd too small");
   GPX_REQUIRE(g.lda < (1L << 21) && g.ldb < (1L << 21), "gemm: leading dimension >= 2^21 (32-bit lane offsets)");
+  // Very long K: the 64 workgroups of a super-tile run without any mutual synchronisation and drift
+  // apart in k until the panels they share no longer meet in the XCD's 4 MiB L2 (measured, M = N = K =
+  // 32768: 71.1 TFLOP/s in one launch, 72.3 as four launches of K = 8192 -- the launch boundary
+  // re-aligns them; the extra pass over C costs 2 ms of HBM time per boundary, under the MFMAs).
+  // Plain operands only: a triangular operand's k range is tied to the tile position.
+  static const long kchunk = [] {
+    const char* e = getenv("GPX_GEMM_KCHUNK");   // development override; 0 disables
+    return e ? atol(e) : 8192L;
+  }();
+  if (kchunk > 0 && g.K >= 2 * kchunk && !g.a_tri && !g.b_tri && !g.inplace && g.split_s <= 1 &&
+      (long)g.M * g.N >= 4096L * 4096L) {
+    GemmDesc c = g;
+    for (int k0 = 0; k0 < g.K; k0 += c.K) {
+      c.K = g.K - k0 < 2 * kchunk ? g.K - k0 : (int)kchunk;   // the last chunk takes the remainder (< 2 chunks: no recursion)
+      c.A = g.a_lay == GPX_LAY_KC ? g.A + k0 : g.A + (long)k0 * g.lda;
+      c.B = g.b_lay == GPX_LAY_KC ? g.B + k0 : g.B + (long)k0 * g.ldb;
+      if (k0 > 0) { c.Cin = g.D; c.ldcin = g.ldd; c.beta = 1.0; c.diag_add = 0.0; }
+      const int rc = gpx_gemm_launch(s, c);
+      if (rc != 0) return rc;
+    }
+    return 0;
+  }
   // 128 x 128 tiles unless that leaves most of the 256 CUs (2 workgroups each) idle.  In-place
   // launches (D aliases an operand) rely on one workgroup owning a whole operand panel: 128 only.
   const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.c_lower ? 2 : 1);

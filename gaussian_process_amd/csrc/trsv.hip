@@ -3,9 +3,14 @@
 // These are the vector solves of regression.py:50 (a = L^-1 y), regression.py:61 (the second half
 // of cho_solve) and expectation_propagation.py:63,92.  The factor is read exactly once: the
 // recursion  [L11 0; L21 L22]  ->  solve(L11), x2 -= L21 x1 (GEMV over all CUs), solve(L22)
-// sends every off-diagonal element through one streaming GEMV, and the diagonal leaves (<= 1024
-// rows) are solved by one workgroup from the 128x128 diagonal-block inverses gpx_potrf left in
-// dinv (so the leaf is two small mat-vecs per block, no divisions, no scalar recurrence).
+// sends every off-diagonal element through one streaming GEMV, and the diagonal leaves (256 rows)
+// are solved by one workgroup from the 128x128 diagonal-block inverses gpx_potrf left in dinv (so
+// the leaf is three small mat-vecs, no divisions, no scalar recurrence).
+// The n / 256 dependent leaves are the critical chain (~9 us each, 2.4 ms at n = 65536) and come on
+// top of the streaming part.  Running the streaming GEMVs on a second stream beside the chain was
+// built and measured (blocks of 2048 rows, the GEMV of a block two blocks behind the chain): the
+// leaves' loads then queue behind the saturated HBM, a leaf takes 21 us instead of 10, and the solve
+// got slower (7.1 / 7.4 ms against 6.6 / 6.9 ms one after the other) -- not kept.
 // Algorithmic bytes: 4 n^2 (lower triangle of L) + 64 KiB per diagonal block of dinv.
 // All reductions have a fixed association order: results are bitwise reproducible.
 #include <cstdlib>
@@ -17,156 +22,176 @@ namespace {
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int NB = GPX_NB;
-constexpr int LEAF_MAX = 1024;      // rows a leaf workgroup can hold
+constexpr int LEAF_ROWS = 256;      // rows of a leaf (two 128-blocks; 512 -> 8.0 / 13.8 ms, 1024 -> 10.1 / 22.2 ms at n = 65536 before the prefetching leaf)
 constexpr int LEAF_THREADS = 512;   // 8 waves
 constexpr int XCHUNK = 2048;        // columns of x staged per pass in the GEMV
 
-// ---- 16 lanes per row: a lane owns 8 consecutive columns (4 x 16-byte loads) of a 128-column
-// segment; 4 rows per wave and pass.  seg_partial = the lane's share of the dot product.
+// ---- 16 lanes per row of a 128-column segment; a lane owns the four 16-byte pieces at columns
+// 2 l16 + 32 q, q = 0..3, so that ONE load instruction of the wave reads 256 contiguous bytes of each
+// of its 4 rows (whole 128-byte lines; with 8 consecutive columns per lane an instruction touched
+// every line of the segment for a quarter of its bytes, and the leaf ran at 21 us instead of 8).
+// seg_partial = the lane's share of the dot product.
 struct Seg { v2d a0, a1, a2, a3; };
 
 __device__ __forceinline__ Seg seg_load(const double* row128, int l16) {
-  const v2d* p = reinterpret_cast<const v2d*>(row128 + l16 * 8);
+  const v2d* p = reinterpret_cast<const v2d*>(row128 + l16 * 2);
   Seg s;
-  s.a0 = p[0]; s.a1 = p[1]; s.a2 = p[2]; s.a3 = p[3];
+  s.a0 = p[0]; s.a1 = p[16]; s.a2 = p[32]; s.a3 = p[48];
   return s;
 }
 
 __device__ __forceinline__ double seg_partial(const Seg& s, const double* x128, int l16, double acc) {
-  const double* x = x128 + l16 * 8;
+  const double* x = x128 + l16 * 2;
   acc = fma(s.a0.x, x[0], acc);
   acc = fma(s.a0.y, x[1], acc);
-  acc = fma(s.a1.x, x[2], acc);
-  acc = fma(s.a1.y, x[3], acc);
-  acc = fma(s.a2.x, x[4], acc);
-  acc = fma(s.a2.y, x[5], acc);
-  acc = fma(s.a3.x, x[6], acc);
-  acc = fma(s.a3.y, x[7], acc);
+  acc = fma(s.a1.x, x[32], acc);
+  acc = fma(s.a1.y, x[33], acc);
+  acc = fma(s.a2.x, x[64], acc);
+  acc = fma(s.a2.y, x[65], acc);
+  acc = fma(s.a3.x, x[96], acc);
+  acc = fma(s.a3.y, x[97], acc);
   return acc;
 }
 
-// sum over the 16 lanes of a row group (every lane of the group gets the total)
+// sum over the 16 lanes of a row group (every lane of the group gets the total): the 16 lanes are one
+// DPP row, so each step is a row rotation folded into two v_mov_dpp (no LDS crossbar round trip as
+// with __shfl_xor; the forward leaf runs 12 of these reductions on its critical path)
+template <int CTRL>
+__device__ __forceinline__ double dpp_rot(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 __device__ __forceinline__ double group16_sum(double v) {
-  v += __shfl_xor(v, 8, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 1, 16);
+  v += dpp_rot<0x128>(v);   // row_ror:8
+  v += dpp_rot<0x124>(v);   // row_ror:4
+  v += dpp_rot<0x122>(v);   // row_ror:2
+  v += dpp_rot<0x121>(v);   // row_ror:1
   return v;
 }
 
-// ---- forward leaf: x <- L^-1 x for n <= LEAF_MAX rows, one workgroup --------------------------
+// ---- leaves: n <= 256 rows (at most two 128-blocks), one workgroup of 512 threads ----------------
+// Everything a leaf reads from HBM -- dinv_0, the off-diagonal block L10 and dinv_1, 384 KiB -- is
+// requested before the first use (96 doubles per thread in registers), so the leaf pays ONE memory
+// latency instead of one per dependent step (12.5 -> ~6 us per leaf; 256 of them form the critical
+// chain of a solve at n = 65536).
+
+// forward: x <- L^-1 x.  Lane (wave wid, group g, l16) owns 8 consecutive columns of rows
+// p * 32 + wid * 4 + g, p = 0..3, of each 128 x 128 block.
 __global__ __launch_bounds__(LEAF_THREADS) void trsv_leaf_fwd_kernel(int n, const double* L, long ldl,
                                                                      const double* dinv, double* x,
                                                                      long incx) {
-  __shared__ double xs[LEAF_MAX];
-  __shared__ double ys[NB];
+  __shared__ double xs[LEAF_ROWS];   // right-hand side
+  __shared__ double xo[LEAF_ROWS];   // solution
+  __shared__ double rs[NB];          // updated right-hand side of the second block
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, g = lane >> 4, l16 = lane & 15;
-  for (int i = t; i < LEAF_MAX; i += LEAF_THREADS) xs[i] = i < n ? x[(long)i * incx] : 0.0;
+  const bool two = n > NB;
+  Seg d0[4], l10[4], d1[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) d0[p] = seg_load(dinv + (p * 32 + wid * 4 + g) * NB, l16);
+  if (two) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) l10[p] = seg_load(L + (long)min(NB + p * 32 + wid * 4 + g, n - 1) * ldl, l16);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) d1[p] = seg_load(dinv + (size_t)NB * NB + (p * 32 + wid * 4 + g) * NB, l16);
+  }
+  if (t < LEAF_ROWS) xs[t] = t < n ? x[(long)t * incx] : 0.0;
   __syncthreads();
-  const int nblk = (n + NB - 1) / NB;
-  for (int b = 0; b < nblk; ++b) {
-    const int b0 = b * NB;
-    // x_b = dinv_b r_b   (dinv blocks are full 128x128, identity-padded past n)
-    const double* D = dinv + (size_t)b * NB * NB;
-    {
-      Seg s[4];
+  // x_0 = dinv_0 r_0 (dinv blocks are full 128 x 128, identity-padded past n)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) s[p] = seg_load(D + (p * 32 + wid * 4 + g) * NB, l16);
+  for (int p = 0; p < 4; ++p) {
+    const double v = group16_sum(seg_partial(d0[p], xs, l16, 0.0));
+    if (l16 == 0) xo[p * 32 + wid * 4 + g] = v;
+  }
+  __syncthreads();
+  if (two) {
+    // r_1 -= L10 x_0, then x_1 = dinv_1 r_1
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const double v = group16_sum(seg_partial(s[p], xs + b0, l16, 0.0));
-        if (l16 == 0) ys[p * 32 + wid * 4 + g] = v;
-      }
+    for (int p = 0; p < 4; ++p) {
+      const int r = p * 32 + wid * 4 + g;
+      const double v = group16_sum(seg_partial(l10[p], xo, l16, 0.0));
+      if (l16 == 0) rs[r] = NB + r < n ? xs[NB + r] - v : 0.0;
     }
     __syncthreads();
-    if (t < NB) xs[b0 + t] = ys[t];
-    __syncthreads();
-    // r_j -= L[j][b0 : b0+128] x_b for the rows below, 32 rows per pass, 4 passes in flight
-    for (int j0 = b0 + NB; j0 < n; j0 += 128) {
-      Seg s[4];
-      int row[4];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        row[p] = j0 + p * 32 + wid * 4 + g;
-        s[p] = seg_load(L + (long)min(row[p], n - 1) * ldl + b0, l16);
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const double v = group16_sum(seg_partial(s[p], xs + b0, l16, 0.0));
-        if (l16 == 0 && row[p] < n) xs[row[p]] -= v;
-      }
+    for (int p = 0; p < 4; ++p) {
+      const double v = group16_sum(seg_partial(d1[p], rs, l16, 0.0));
+      if (l16 == 0) xo[NB + p * 32 + wid * 4 + g] = v;
     }
     __syncthreads();
   }
-  for (int i = t; i < n; i += LEAF_THREADS) x[(long)i * incx] = xs[i];
+  if (t < n) x[(long)t * incx] = xo[t];
 }
 
-// ---- backward leaf: x <- L^-T x ----------------------------------------------------------------
+// backward: x <- L^-T x.  Thread (rg = t / 64, cp = t % 64) owns rows rg * 16 .. + 15 of columns
+// 2 cp, 2 cp + 1 of each block (a wave reads 1 KiB of one row per load); y = M^T v is 8 partial sums
+// per column through LDS.
+struct Blk16 { v2d a[16]; };
+
+__device__ __forceinline__ Blk16 blk_load(const double* M, long ld, int rg, int cp, int row_max) {
+  Blk16 b;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    b.a[i] = *reinterpret_cast<const v2d*>(M + (long)min(rg * 16 + i, row_max) * ld + 2 * cp);
+  return b;
+}
+
+// part[rg][0..127] <- this thread's share of M^T v (v in LDS, 128 entries)
+__device__ __forceinline__ void blk_tmatvec(const Blk16& b, const double* v, double* part, int rg, int cp) {
+  v2d acc = {0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const double xv = v[rg * 16 + i];
+    acc.x = fma(b.a[i].x, xv, acc.x);
+    acc.y = fma(b.a[i].y, xv, acc.y);
+  }
+  part[rg * NB + 2 * cp] = acc.x;
+  part[rg * NB + 2 * cp + 1] = acc.y;
+}
+
+__device__ __forceinline__ double part_sum(const double* part, int j) {
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s += part[q * NB + j];
+  return s;
+}
+
 __global__ __launch_bounds__(LEAF_THREADS) void trsv_leaf_bwd_kernel(int n, const double* L, long ldl,
                                                                      const double* dinv, double* x,
                                                                      long incx) {
-  __shared__ double xs[LEAF_MAX];
-  __shared__ double part[LEAF_MAX];
-  const int t = threadIdx.x;
-  for (int i = t; i < LEAF_MAX; i += LEAF_THREADS) xs[i] = i < n ? x[(long)i * incx] : 0.0;
-  __syncthreads();
-  const int nblk = (n + NB - 1) / NB;
-  for (int b = nblk - 1; b >= 0; --b) {
-    const int b0 = b * NB;
-    const int bw = min(NB, n - b0);
-    // x_b = dinv_b^T r_b : thread (rg, cp) sums 16 rows of two columns, then 8 partials per column
-    {
-      const double* D = dinv + (size_t)b * NB * NB;
-      const int cp = t & 63, rg = t >> 6;
-      v2d acc = {0.0, 0.0};
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = rg * 16 + i;
-        const v2d a = *reinterpret_cast<const v2d*>(D + r * NB + 2 * cp);
-        const double xv = xs[b0 + r];
-        acc.x = fma(a.x, xv, acc.x);
-        acc.y = fma(a.y, xv, acc.y);
-      }
-      part[rg * NB + 2 * cp] = acc.x;
-      part[rg * NB + 2 * cp + 1] = acc.y;
-    }
-    __syncthreads();
-    if (t < NB) {
-      double s = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) s += part[q * NB + t];
-      xs[b0 + t] = s;
-    }
-    __syncthreads();
-    // r_j -= sum_i L[b0+i][j] x_b[i] for the columns j < b0
-    if (b0 > 0) {
-      const int C = b0, pairs = C / 2;
-      const int groups = b >= 8 ? 1 : 8 / b;          // row groups so that all 512 threads work
-      const int rpg = (NB + groups - 1) / groups;
-      for (int item = t; item < groups * pairs; item += LEAF_THREADS) {
-        const int gq = item / pairs, p = item - gq * pairs;
-        const int i1 = min(bw, (gq + 1) * rpg);
-        v2d acc = {0.0, 0.0};
-#pragma unroll 8
-        for (int i = gq * rpg; i < i1; ++i) {
-          const v2d a = *reinterpret_cast<const v2d*>(L + (long)(b0 + i) * ldl + 2 * p);
-          const double xv = xs[b0 + i];
-          acc.x = fma(a.x, xv, acc.x);
-          acc.y = fma(a.y, xv, acc.y);
-        }
-        part[gq * C + 2 * p] = acc.x;
-        part[gq * C + 2 * p + 1] = acc.y;
-      }
-      __syncthreads();
-      for (int j = t; j < C; j += LEAF_THREADS) {
-        double s = 0.0;
-        for (int q = 0; q < groups; ++q) s += part[q * C + j];
-        xs[j] -= s;
-      }
-      __syncthreads();
-    }
+  __shared__ double xs[LEAF_ROWS];
+  __shared__ double xo[LEAF_ROWS];
+  __shared__ double part[8 * NB];
+  const int t = threadIdx.x, cp = t & 63, rg = t >> 6;
+  const bool two = n > NB;
+  Blk16 d1, l10, d0;
+  if (two) {
+    d1 = blk_load(dinv + (size_t)NB * NB, NB, rg, cp, NB - 1);
+    l10 = blk_load(L + (long)NB * ldl, ldl, rg, cp, n - 1 - NB);   // rows past n are clamped; their x is zero
   }
-  for (int i = t; i < n; i += LEAF_THREADS) x[(long)i * incx] = xs[i];
+  d0 = blk_load(dinv, NB, rg, cp, NB - 1);
+  if (t < LEAF_ROWS) xs[t] = t < n ? x[(long)t * incx] : 0.0;
+  __syncthreads();
+  if (two) {
+    // x_1 = dinv_1^T r_1
+    blk_tmatvec(d1, xs + NB, part, rg, cp);
+    __syncthreads();
+    if (t < NB) xo[NB + t] = part_sum(part, t);
+    __syncthreads();
+    // r_0 -= L10^T x_1
+    blk_tmatvec(l10, xo + NB, part, rg, cp);
+    __syncthreads();
+    if (t < NB) xs[t] -= part_sum(part, t);
+    __syncthreads();
+  }
+  // x_0 = dinv_0^T r_0
+  blk_tmatvec(d0, xs, part, rg, cp);
+  __syncthreads();
+  if (t < NB) xo[t] = part_sum(part, t);
+  __syncthreads();
+  if (t < n) x[(long)t * incx] = xo[t];
 }
 
 // ---- x2 -= A x1, A n2 x n1 row-major (n1 a multiple of 128): 16 rows per workgroup -------------
@@ -196,27 +221,44 @@ __global__ __launch_bounds__(256) void trsv_gemvn_kernel(int n2, int n1, const d
   if (l16 == 0 && r < n2) x2[(long)r * incx] -= acc;
 }
 
-// ---- x1 -= A^T x2: per row chunk partial column sums, then a fixed-order final pass ------------
+// ---- x1 -= A^T x2 (A n2 x n1 row-major): column sums per row chunk, then a fixed-order final pass ----
+// A workgroup owns a strip of 128 columns (a wave reads 1 KiB of one row per load) and a chunk of
+// `rc` rows; its 4 waves take every 4th row, so a thread walks rc / 4 rows with the loads of 8 rows in
+// flight (one thread per column pair walking all rc rows left the small GEMVs of the chain
+// latency-bound: 18 us each).  The chunk's column sums go to partials[chunk][col].
+// (Combining the chunks in the same launch -- last workgroup of a strip by ticket counter -- was
+// measured and lost by 10x: a device-scope release / acquire on this multi-XCD part writes back and
+// invalidates the XCD's L2 for every workgroup; the kernel boundary does it once.)
 __global__ __launch_bounds__(256) void trsv_gemvt_partial_kernel(int n2, int n1, const double* A, long lda,
                                                                  const double* x2, long incx, int rc,
                                                                  double* partials) {
   __shared__ double xs[XCHUNK];
-  const int t = threadIdx.x;
-  const int col = (blockIdx.x * 256 + t) * 2;
-  const int i0 = blockIdx.y * rc, i1 = min(n2, i0 + rc);
+  __shared__ v2d red[4][64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int chunk = blockIdx.y;
+  const int col = blockIdx.x * NB + 2 * lane;
+  const int i0 = chunk * rc, i1 = min(n2, i0 + rc);
   for (int i = t; i < i1 - i0; i += 256) xs[i] = x2[(long)(i0 + i) * incx];
   __syncthreads();
-  if (col >= n1) return;
-  const double* a = A + (long)i0 * lda + col;
+  const int cc = min(col, n1 - 2);   // n1 is a multiple of 128 on every path; the clamp keeps the loads in range anyway
+  const double* a = A + (long)i0 * lda + cc;
   v2d acc = {0.0, 0.0};
 #pragma unroll 8
-  for (int i = 0; i < i1 - i0; ++i) {
+  for (int i = w; i < i1 - i0; i += 4) {
     const v2d v = *reinterpret_cast<const v2d*>(a + (long)i * lda);
     const double xv = xs[i];
     acc.x = fma(v.x, xv, acc.x);
     acc.y = fma(v.y, xv, acc.y);
   }
-  *reinterpret_cast<v2d*>(partials + (size_t)blockIdx.y * n1 + col) = acc;
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && col < n1) {
+    v2d s = red[0][lane];
+    s += red[1][lane];
+    s += red[2][lane];
+    s += red[3][lane];
+    *reinterpret_cast<v2d*>(partials + (size_t)chunk * n1 + col) = s;
+  }
 }
 
 __global__ __launch_bounds__(256) void trsv_gemvt_final_kernel(int nchunks, int n1, const double* partials,
@@ -224,21 +266,9 @@ __global__ __launch_bounds__(256) void trsv_gemvt_final_kernel(int nchunks, int 
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n1) return;
   double s = 0.0;
+#pragma unroll 4
   for (int c = 0; c < nchunks; ++c) s += partials[(size_t)c * n1 + j];
   x1[(long)j * incx] -= s;
-}
-
-int g_leaf = 0;  // rows per leaf; 0 = not yet initialised (GPX_TRSV_LEAF overrides, development only)
-
-inline int leaf_rows() {
-  if (g_leaf == 0) {
-    g_leaf = 256;  // measured at n = 65536: 256 -> 7.3 / 11.0 ms (fwd / bwd), 512 -> 8.0 / 13.8, 1024 -> 10.1 / 22.2
-    if (const char* e = getenv("GPX_TRSV_LEAF")) {
-      const int v = atoi(e);
-      if (v >= NB && v <= LEAF_MAX && v % NB == 0) g_leaf = v;
-    }
-  }
-  return g_leaf;
 }
 
 inline int split_rows(int n) {
@@ -247,8 +277,34 @@ inline int split_rows(int n) {
   return h;
 }
 
+int launch_gemvn(hipStream_t s, int n2, int n1, const double* A, long lda, const double* x1, double* x2, long incx) {
+  hipLaunchKernelGGL(trsv_gemvn_kernel, dim3((n2 + 15) / 16), dim3(256), 0, s, n2, n1, A, lda, x1, x2, incx);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// x1 -= A^T x2 (A n2 x n1): column sums per row chunk into `red`, then the fixed-order final pass
+int launch_gemvt(hipStream_t s, int n2, int n1, const double* A, long lda, const double* x2, double* x1, long incx,
+                 double* red, size_t red_elems) {
+  // rows per chunk: enough workgroups to pull the block at HBM speed (a chunk of 128 rows x 128 columns is
+  // 128 KiB), shorter chunks when the block is small, longer ones when the partials would not fit
+  int rows = n2 * (long)n1 <= 1024L * 1024 ? 64 : NB;
+  while ((size_t)((n2 + rows - 1) / rows) * n1 > red_elems && rows < XCHUNK) rows *= 2;
+  const int nchunks = (n2 + rows - 1) / rows;
+  if ((size_t)nchunks * n1 > red_elems) {
+    gpx_set_error("trsv: reduction scratch too small (%d x %d block)", n2, n1);
+    return GPX_ENOMEM;
+  }
+  hipLaunchKernelGGL(trsv_gemvt_partial_kernel, dim3((n1 + NB - 1) / NB, nchunks), dim3(256), 0, s, n2, n1, A, lda,
+                     x2, incx, rows, red);
+  GPX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(trsv_gemvt_final_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, nchunks, n1, red, x1, incx);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
 int fwd(hipStream_t s, int n, const double* L, long ldl, const double* dinv, double* x, long incx) {
-  if (n <= leaf_rows()) {
+  if (n <= LEAF_ROWS) {
     hipLaunchKernelGGL(trsv_leaf_fwd_kernel, dim3(1), dim3(LEAF_THREADS), 0, s, n, L, ldl, dinv, x, incx);
     GPX_HIP(hipGetLastError());
     return 0;
@@ -256,15 +312,14 @@ int fwd(hipStream_t s, int n, const double* L, long ldl, const double* dinv, dou
   const int n1 = split_rows(n), n2 = n - n1;
   int rc = fwd(s, n1, L, ldl, dinv, x, incx);
   if (rc != 0) return rc;
-  hipLaunchKernelGGL(trsv_gemvn_kernel, dim3((n2 + 15) / 16), dim3(256), 0, s, n2, n1, L + (long)n1 * ldl, ldl,
-                     x, x + (long)n1 * incx, incx);
-  GPX_HIP(hipGetLastError());
+  rc = launch_gemvn(s, n2, n1, L + (long)n1 * ldl, ldl, x, x + (long)n1 * incx, incx);
+  if (rc != 0) return rc;
   return fwd(s, n2, L + (long)n1 * ldl + n1, ldl, dinv + (size_t)(n1 / NB) * NB * NB, x + (long)n1 * incx, incx);
 }
 
 int bwd(hipStream_t s, int n, const double* L, long ldl, const double* dinv, double* x, long incx,
         double* red, size_t red_elems) {
-  if (n <= leaf_rows()) {
+  if (n <= LEAF_ROWS) {
     hipLaunchKernelGGL(trsv_leaf_bwd_kernel, dim3(1), dim3(LEAF_THREADS), 0, s, n, L, ldl, dinv, x, incx);
     GPX_HIP(hipGetLastError());
     return 0;
@@ -273,19 +328,8 @@ int bwd(hipStream_t s, int n, const double* L, long ldl, const double* dinv, dou
   int rc = bwd(s, n2, L + (long)n1 * ldl + n1, ldl, dinv + (size_t)(n1 / NB) * NB * NB, x + (long)n1 * incx,
                incx, red, red_elems);
   if (rc != 0) return rc;
-  // rows per chunk: as small as the partials buffer allows (more workgroups), at most XCHUNK
-  int rows = NB;
-  while ((size_t)((n2 + rows - 1) / rows) * n1 > red_elems && rows < XCHUNK) rows *= 2;
-  const int nchunks = (n2 + rows - 1) / rows;
-  if ((size_t)nchunks * n1 > red_elems) {
-    gpx_set_error("trsv: reduction scratch too small for n=%d", n);
-    return GPX_ENOMEM;
-  }
-  hipLaunchKernelGGL(trsv_gemvt_partial_kernel, dim3((n1 / 2 + 255) / 256, nchunks), dim3(256), 0, s, n2, n1,
-                     L + (long)n1 * ldl, ldl, x + (long)n1 * incx, incx, rows, red);
-  GPX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(trsv_gemvt_final_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, nchunks, n1, red, x, incx);
-  GPX_HIP(hipGetLastError());
+  rc = launch_gemvt(s, n2, n1, L + (long)n1 * ldl, ldl, x + (long)n1 * incx, x, incx, red, red_elems);
+  if (rc != 0) return rc;
   return bwd(s, n1, L, ldl, dinv, x, incx, red, red_elems);
 }
 

@@ -173,7 +173,7 @@ def test_potrf_trsm_trtri_lauum(rt, n):
     assert relerr(down(rt, Kinv, n, n), np.linalg.inv(A)) < 1e-12
 
 
-@pytest.mark.parametrize("n", [513, 1024, 1153, 4097, 9000])
+@pytest.mark.parametrize("n", [100, 257, 513, 1024, 1153, 4097, 9000, 16500])
 def test_trsv_single_rhs(rt, n):
     """One right-hand side goes through the streaming TRSV (leaf + GEMV recursion), both directions,
     including strided vectors; the factor here is a generic lower-triangular matrix, not a Cholesky
