@@ -68,8 +68,8 @@ def single_gpu_step(rt, lib, bufs, cfg, timer, check):
     called one by one so every stage can be bracketed by events)."""
     from gaussian_process_amd import _lib
     n, m, d = cfg["n"], cfg["m"], cfg["d"]
-    X, y, Xs, Ky, Kinv, dinv, V, cov, vec2, a_vec, al_vec, mean = (
-        bufs[k] for k in ("X", "y", "Xs", "Ky", "Kinv", "dinv", "V", "cov", "vec2", "a", "alpha", "mean"))
+    X, y, Xs, Ky, kdiag, dinv, V, cov, vec2, a_vec, al_vec, mean = (
+        bufs[k] for k in ("X", "y", "Xs", "Ky", "kdiag", "dinv", "V", "cov", "vec2", "a", "alpha", "mean"))
     ld = Ky.shape[1]
     beta_arr, beta_p = _lib.host_doubles(cfg["beta"])
     kind = _lib.GPX_KIND["ard"]
@@ -94,12 +94,14 @@ def single_gpu_step(rt, lib, bufs, cfg, timer, check):
                               P(dinv), P(Xs), m, Xs.shape[1], P(V), V.shape[1], P(bufs["vec4"]), P(mean),
                               P(cov), cov.shape[1], None, 1), "predict")
     timer.mark("predict")
-    check(lib.gpx_trtri(rt.h, n, P(Ky), ld, P(dinv), P(Kinv)), "trtri")
+    # the gradient in the factor's own buffer: W = L^-1 in the lower triangle, Ky^-1 = W^T W in the strict
+    # upper triangle (diagonal in kdiag), read from there by the trace kernel
+    check(lib.gpx_trtri(rt.h, n, P(Ky), ld, P(dinv)), "trtri")
     timer.mark("trtri")
-    check(lib.gpx_lauum(rt.h, n, P(Ky), ld, P(Kinv), ld), "lauum")
+    check(lib.gpx_lauum_upper(rt.h, n, P(Ky), ld, P(kdiag)), "lauum")
     timer.mark("lauum")
     grad = (C.c_double * (2 + d))()
-    check(lib.gpx_grad_trace(rt.h, kind, P(X), n, X.shape[1], d, sig, beta_p, P(al_vec), P(Kinv), ld,
+    check(lib.gpx_grad_trace(rt.h, kind, P(X), n, X.shape[1], d, sig, beta_p, P(al_vec), P(Ky), ld, P(kdiag),
                              C.cast(grad, C.POINTER(C.c_double))), "grad_trace")
     timer.mark("grad_trace")
     return lml, np.array(list(grad))
@@ -126,10 +128,11 @@ def dominant_launch(rt, lib, bufs, check, torch, size=16384, reps=3):
     update of a 32768 split is this shape, lower tiles only): D = C - A B^T, M = N = K = size,
     timed by HIP events on the launch stream.  Algorithmic flops 2 M N K; algorithmic bytes
     8 (MK + NK + 2 MN) (operands once, C read + written)."""
-    Kinv, Ky = bufs["Kinv"], bufs["Ky"]
+    Ky = bufs["Ky"]
     ld = Ky.shape[1]
-    a = Kinv[:size, :size]
-    b = Kinv[size:2 * size, :size]
+    assert Ky.shape[0] >= 2 * size, "dominant launch needs n >= %d" % (2 * size)
+    a = Ky[size:2 * size, :size]            # operands: whatever the last step left in the buffer (finite values)
+    b = Ky[:size, :size]
     c = Ky[:size, size:2 * size]            # strictly upper part of the Ky buffer: scratch here
     c.zero_()
     ms = []
@@ -159,7 +162,20 @@ def launch_traffic():
     return None
 
 
-def cpu_baseline(n_cpu, m_cpu, reps=3):
+def cpu_baseline(n_cpu, m_cpu):
+    """The CPU baseline in a fresh child process (`bench.py --cpu-only`): no torch, no HIP runtime and no
+    OpenMP pool of theirs beside the BLAS threads -- inside the benchmark process the same Cholesky ran up to
+    8x slower (0.034 against 0.27 TFLOP/s).  The child never touches the GPU."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-only", "--cpu-n", str(n_cpu), "--cpu-m", str(m_cpu)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900, check=True)
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:   # the GPU line must not be lost to a host-side failure
+        return {"value": None, "unit": "TFLOP/s", "cores": 0, "kind": "port", "sample": "cpu baseline failed: %r" % (e,)}
+
+
+def cpu_baseline_run(n_cpu, m_cpu, reps=3):
     """The oracle (CPU restatement of the reference's path) on a bounded sample of the same workload,
     all host cores the BLAS is given; stages timed separately, best of `reps` (the O(n^3) inverse of the
     gradient once).  value = n^3/3 / Cholesky time in the metric's unit."""
@@ -173,6 +189,7 @@ def cpu_baseline(n_cpu, m_cpu, reps=3):
             t0 = time.perf_counter()
             out = fn()
             ts.append(time.perf_counter() - t0)
+            print("cpu_baseline n=%d: stage run %.2f s" % (n_cpu, ts[-1]), file=sys.stderr, flush=True)   # progress
         return min(ts), out
 
     def gram():
@@ -244,14 +261,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ntrain", "--n", dest="n", type=int, default=65536)   # (torchrun mis-parses a bare --n)
     ap.add_argument("--ntest", "--m", dest="m", type=int, default=4096)
-    ap.add_argument("--cpu-n", type=int, default=8192,
-                    help="size of the CPU-baseline sample (SURVEY 8d asks for 16384: ~6 min of host time, "
-                         "recorded once in profiles/; the default keeps the whole run within minutes)")
+    ap.add_argument("--cpu-n", type=int, default=16384,
+                    help="size of the CPU-baseline sample (SURVEY 8d: n = 16384, about one minute of host time)")
+    ap.add_argument("--cpu-m", type=int, default=512)
     ap.add_argument("--no-public-api", action="store_true")
     ap.add_argument("--block", type=int, default=0,
                     help="block-column width of the multi-GPU Cholesky (0: 2048 on 1-2 ranks, 1024 on 4, 512 on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-only", action="store_true",
+                    help="run only the CPU baseline (--cpu-n, --cpu-m) in this process and print it; no GPU is touched")
     args = ap.parse_args()
+    if args.cpu_only:
+        print(json.dumps(cpu_baseline_run(args.cpu_n, args.cpu_m)))
+        return 0
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,7 +281,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("GPX_FORCE_DIST"):   # env: run the N>1 code on 1 rank
         from gaussian_process_amd import dist_bench
-        base = None if args.no_cpu_baseline else (lambda: cpu_baseline(args.cpu_n, 512))
+        base = None if args.no_cpu_baseline else (lambda: cpu_baseline(args.cpu_n, args.cpu_m))
         return dist_bench.main(args, rank, local_rank, world, cpu_baseline=base, traffic=launch_traffic())
 
     torch.cuda.set_device(0)
@@ -277,7 +299,7 @@ def main():
     X, y, Xs, beta = synthetic_ard(n, m=m, d=d, seed=0, noise=0.1)
     cfg = dict(n=n, m=m, d=d, beta=beta, sigma=1.0, noise=0.1)
     bufs = dict(X=rt.upload_matrix(X), y=rt.upload_vector(y), Xs=rt.upload_matrix(Xs),
-                Ky=rt.matrix(n, n), Kinv=rt.matrix(n, n), dinv=rt.dinv(n), V=rt.matrix(n, m),
+                Ky=rt.matrix(n, n), kdiag=rt.vector(n), dinv=rt.dinv(n), V=rt.matrix(n, m),
                 cov=rt.matrix(m, m), vec2=torch.zeros((n, 2), dtype=torch.float64, device=rt.dev),
                 vec4=rt.vector(4 * n), a=rt.vector(n), alpha=rt.vector(n), mean=rt.vector(m))
     for _ in range(args.warmup):
@@ -337,7 +359,7 @@ def main():
         torch.cuda.empty_cache()
         out["public_api"] = public_api_leg(X, y, Xs, beta, torch)
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_n, 512)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_m)
     print(json.dumps(out))
 
 

@@ -25,7 +25,6 @@ SIGNATURES = {
     "gpx_last_error": (C.c_char_p, []),
     "gpx_version": (C.c_char_p, []),
     "gpx_dinv_elems": (_sz, [_i]),
-    "gpx_trtri_work_elems": (_sz, [_i]),
     "gpx_gram": (_i, [C.c_void_p, _i, _dp, _i, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _i, _i]),
     "gpx_gram_dtheta": (_i, [C.c_void_p, _i, _dp, _i, _i, _dp, _i, _i, _i, _d, _hp, _dp, _dp, _dp, _i, _sz]),
     "gpx_potrf": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
@@ -34,8 +33,9 @@ SIGNATURES = {
     "gpx_diag_inv": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
     "gpx_trsm": (_i, [C.c_void_p, _i, _i, _i, _dp, _i, _dp, _dp, _i]),
     "gpx_logdet": (_i, [C.c_void_p, _i, _dp, _i, _hp]),
-    "gpx_trtri": (_i, [C.c_void_p, _i, _dp, _i, _dp, _dp]),
+    "gpx_trtri": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
     "gpx_lauum": (_i, [C.c_void_p, _i, _dp, _i, _dp, _i]),
+    "gpx_lauum_upper": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
     "gpx_syrk_sub": (_i, [C.c_void_p, _i, _i, _dp, _i, _dp, _i, _d, _i]),
     "gpx_gemm": (_i, [C.c_void_p, _i, _i, _i, _i, _i, _d, _dp, _i, _dp, _i, _d, _dp, _i]),
     "gpx_trmm": (_i, [C.c_void_p, _i, _i, _dp, _i, _dp, _i, _dp, _i]),
@@ -46,9 +46,9 @@ SIGNATURES = {
     "gpx_dot": (_i, [C.c_void_p, _i, _dp, _dp, _hp]),
     "gpx_symmetrize": (_i, [C.c_void_p, _i, _dp, _i]),
     "gpx_diag": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
-    "gpx_grad_trace": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _dp, _dp, _i, _hp]),
+    "gpx_grad_trace": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _dp, _dp, _i, _dp, _hp]),
     "gpx_grad_trace_slab": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _dp, _dp, _i, _i, _i, _i, _i, _hp]),
-    "gpx_gpr_lml_grad": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _dp, _i, _dp, _dp,
+    "gpx_gpr_lml_grad": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _dp,
                               _dp, _dp, _hp, _hp]),
     "gpx_gpr_predict": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _dp, _i, _i,
                              _dp, _i, _dp, _dp, _dp, _i, _dp, _i]),

@@ -221,6 +221,11 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
     bid = g.split_tile0 + bid / (unsigned)g.split_s;
   }
   if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bid, order, bi, bj)) return;
+  if (g.c_upper) {   // mirror image of the lower enumeration (symmetric product): tile (bj, bi) on or above the diagonal
+    const int tmp = bi;
+    bi = bj;
+    bj = tmp;
+  }
   const int i0 = bi * BM, j0 = bj * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
@@ -452,7 +457,13 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
         double v = alpha * acc[x][y][r];
         if (use_c) v += beta * cv[r][y];
         if (row == col) v += g.diag_add;
-        const bool ok = row < g.M && col < g.N && (!g.c_lower || col <= row);
+        bool ok = row < g.M && col < g.N;
+        if (g.c_upper) {
+          if (row == col && ok) g.diag_out[row] = v;
+          ok = ok && col > row;
+        } else if (g.c_lower) {
+          ok = ok && col <= row;
+        }
         if (ok) g.D[(long)row * g.ldd + col] = v;
       }
     }
@@ -607,7 +618,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     const unsigned main_tiles = (unsigned)(ntiles - rem);
     launch(dim3(main_tiles), 0, 0);
     int split = 0;
-    if (splitk_on && t_ws != nullptr && rem <= 128 && g.K >= 1024 && !g.a_tri && !g.b_tri && !g.inplace) {
+    if (splitk_on && t_ws != nullptr && rem <= 128 && g.K >= 1024 && !g.a_tri && !g.b_tri && !g.inplace && !g.c_upper) {
       split = (int)(256 / rem);
       while (split > 1 && g.K / split < 128) --split;
       if ((size_t)rem * split * (BM * BN) > t_ws_elems) split = (int)(t_ws_elems / ((size_t)rem * BM * BN));
@@ -655,6 +666,8 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   GPX_REQUIRE(g.K >= 0, "gemm: negative K");
   GPX_REQUIRE(g.A && g.B && g.D, "gemm: null operand");
   GPX_REQUIRE(g.beta == 0.0 || g.Cin, "gemm: beta != 0 needs Cin");
+  GPX_REQUIRE(!g.c_upper || (g.c_lower && g.diag_out && g.M == g.N && g.beta == 0.0),
+              "gemm: c_upper needs c_lower, a diagonal vector, a square product and beta = 0");
   GPX_REQUIRE(gpx_aligned16(g.A) && gpx_aligned16(g.B), "gemm: operands must be 16-byte aligned");
   GPX_REQUIRE((g.lda & 1) == 0 && (g.ldb & 1) == 0, "gemm: leading dimensions must be even");
   GPX_REQUIRE(g.lda >= (g.a_lay == GPX_LAY_KC ? g.K : g.M), "gemm: lda too small");
@@ -670,7 +683,7 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
     const char* e = getenv("GPX_GEMM_KCHUNK");   // development override; 0 disables
     return e ? atol(e) : 8192L;
   }();
-  if (kchunk > 0 && g.K >= 2 * kchunk && !g.a_tri && !g.b_tri && !g.inplace && g.split_s <= 1 &&
+  if (kchunk > 0 && g.K >= 2 * kchunk && !g.a_tri && !g.b_tri && !g.inplace && !g.c_upper && g.split_s <= 1 &&
       (long)g.M * g.N >= 4096L * 4096L) {
     GemmDesc c = g;
     for (int k0 = 0; k0 < g.K; k0 += c.K) {

@@ -155,23 +155,35 @@ int potrf_rec(hipStream_t s, int n, double* A, long lda, double* dinv, int* info
   return potrf_rec(s, n2, A22, lda, dinv + (size_t)(n1 / NB) * NB * NB, info_dev, off + n1);
 }
 
-// L <- L^-1 in place (lower).  work: >= n2*n1 doubles for the top split.
-int trtri_rec(hipStream_t s, int n, double* L, long ldl, const double* dinv, double* work) {
+// L <- L^-1 in place (lower).  Scratch: the block strictly above the diagonal that mirrors L21 -- rows
+// [0, n1) x columns [n1, n) of the same square, never referenced by a lower-triangular consumer -- holds
+// T^T for T = L21 W11, so the inverse needs no second buffer (every recursion level uses the upper-right
+// block of its own square; they are disjoint).
+int trtri_rec(hipStream_t s, int n, double* L, long ldl, const double* dinv) {
   if (n <= NB) return gpx_copy_dinv_to_diag(s, n, dinv, L, ldl);
   const int n1 = split_point(n), n2 = n - n1;
   double* L21 = L + (long)n1 * ldl;
   double* L22 = L21 + n1;
-  GPX_TRY(trtri_rec(s, n1, L, ldl, dinv, work));
-  GPX_TRY(trtri_rec(s, n2, L22, ldl, dinv + (size_t)(n1 / NB) * NB * NB, work));
-  // T = L21 * W11  (W11 lower: stored [k][j], valid j <= k)
-  const long ldt = (n1 + 1) & ~1L;
-  GemmDesc g1 = mk(L21, ldl, GPX_LAY_KC, L, ldl, GPX_LAY_RC, nullptr, 0, work, ldt, n2, n1, n1, 1.0, 0.0);
-  g1.b_tri = 1;
+  double* Tt = L + n1;   // n1 x n2, leading dimension ldl
+  GPX_TRY(trtri_rec(s, n1, L, ldl, dinv));
+  GPX_TRY(trtri_rec(s, n2, L22, ldl, dinv + (size_t)(n1 / NB) * NB * NB));
+  // T^T = W11^T L21^T: op(A) = W11^T stored as W11 [k][i] (RC, lower: valid i <= k), op(B) = L21^T stored as
+  // L21 [j][k] (KC)
+  GemmDesc g1 = mk(L, ldl, GPX_LAY_RC, L21, ldl, GPX_LAY_KC, nullptr, 0, Tt, ldl, n1, n2, n1, 1.0, 0.0);
+  g1.a_tri = 1;
   GPX_TRY(gpx_gemm_launch(s, g1));
-  // L21 = -W22 * T  (W22 lower: stored [i][k], valid k <= i)
-  GemmDesc g2 = mk(L22, ldl, GPX_LAY_KC, work, ldt, GPX_LAY_RC, nullptr, 0, L21, ldl, n2, n1, n2, -1.0, 0.0);
+  // L21 = -W22 T: op(A) = W22 (KC, lower: valid k <= i), op(B) = T stored as T^T [j][k] (KC)
+  GemmDesc g2 = mk(L22, ldl, GPX_LAY_KC, Tt, ldl, GPX_LAY_KC, nullptr, 0, L21, ldl, n2, n1, n2, -1.0, 0.0);
   g2.a_tri = 1;
   return gpx_gemm_launch(s, g2);
+}
+
+// strict upper triangle of W's buffer <- Ky^-1 = W^T W (mirror image), diagonal -> kdiag
+int lauum_upper(hipStream_t s, int n, double* W, long ldw, double* kdiag) {
+  GemmDesc g = mk(W, ldw, GPX_LAY_RC, W, ldw, GPX_LAY_RC, nullptr, 0, W, ldw, n, n, n, 1.0, 0.0);
+  g.a_tri = g.b_tri = g.c_lower = g.c_upper = 1;
+  g.diag_out = kdiag;
+  return gpx_gemm_launch(s, g);
 }
 
 int check_mat(const char* what, const void* p, long ld, long mincols) {
@@ -247,12 +259,6 @@ const char* gpx_last_error(void) { return g_err; }
 const char* gpx_version(void) { return "gpx 0.1 (gfx950, fp64 MFMA 16x16x4)"; }
 
 size_t gpx_dinv_elems(int n) { return n <= 0 ? 0 : (size_t)((n + NB - 1) / NB) * NB * NB; }
-
-size_t gpx_trtri_work_elems(int n) {
-  if (n <= NB) return 2;
-  const int n1 = split_point(n), n2 = n - n1;
-  return (size_t)n2 * ((n1 + 1) & ~1);
-}
 
 int gpx_create(gpx_handle** out, int device) {
   GPX_REQUIRE(out != nullptr, "gpx_create: null output");
@@ -416,13 +422,22 @@ int gpx_dot(gpx_handle* h, int n, const double* x, const double* y, double* out_
   return fetch(h, sc, out_host, 1);
 }
 
-int gpx_trtri(gpx_handle* h, int n, double* L, int ldl, const double* dinv, double* work) {
+int gpx_trtri(gpx_handle* h, int n, double* L, int ldl, const double* dinv) {
   GPX_REQUIRE(h != nullptr, "null handle");
   if (n <= 0) return 0;
   GPX_TRY(check_mat("trtri: L", L, ldl, n));
-  GPX_REQUIRE(dinv != nullptr && work != nullptr && gpx_aligned16(work), "trtri: null/misaligned workspace");
+  GPX_REQUIRE(dinv != nullptr, "trtri: null dinv");
   DeviceGuard dg(h);
-  return trtri_rec(h->stream, n, L, ldl, dinv, work);
+  return trtri_rec(h->stream, n, L, ldl, dinv);
+}
+
+int gpx_lauum_upper(gpx_handle* h, int n, double* W, int ldw, double* kdiag) {
+  GPX_REQUIRE(h != nullptr, "null handle");
+  if (n <= 0) return 0;
+  GPX_TRY(check_mat("lauum_upper: W", W, ldw, n));
+  GPX_REQUIRE(kdiag != nullptr, "lauum_upper: null diagonal vector");
+  DeviceGuard dg(h);
+  return lauum_upper(h->stream, n, W, ldw, kdiag);
 }
 
 int gpx_lauum(gpx_handle* h, int n, const double* W, int ldw, double* Kinv, int ldk) {
@@ -526,7 +541,7 @@ static int finish_grad(int nbeta, double sigma, const BetaArg& b, const double* 
 
 int gpx_grad_trace(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
                    const double* beta_host, const double* alpha, const double* Kinv, int ldk,
-                   double* out_host) {
+                   const double* kdiag, double* out_host) {
   GPX_REQUIRE(h != nullptr && out_host != nullptr, "grad_trace: null argument");
   BetaArg b;
   int nbeta;
@@ -537,7 +552,7 @@ int gpx_grad_trace(gpx_handle* h, int kind, const double* X, int n, int ldx, int
   DeviceGuard dg(h);
   double* sc = red_scalars(h);
   GPX_TRY(gpx_grad_trace_launch(h->stream, X, ldx, d, nbeta, sigma, b, alpha, Kinv, ldk, 0, 0, n, n, h->red,
-                                RED_USABLE, sc));
+                                RED_USABLE, sc, kdiag));
   double raw[GPX_MAXD + 2];
   GPX_TRY(fetch(h, sc, raw, 2 + nbeta));
   return finish_grad(nbeta, sigma, b, raw, out_host);
@@ -568,7 +583,7 @@ int gpx_grad_trace_slab(gpx_handle* h, int kind, const double* X, int n, int ldx
 
 int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, int d,
                      double sigma, const double* beta_host, double noise, const double* y,
-                     double* Ky, double* Kinv, int ldk, double* dinv, double* vec,
+                     double* Ky, int ldk, double* dinv, double* vec,
                      double* alpha_out, double* a_out, double* lml_host, double* grad_host) {
   GPX_REQUIRE(h != nullptr && lml_host != nullptr, "gpr_lml_grad: null argument");
   BetaArg b;
@@ -577,11 +592,8 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
   GPX_REQUIRE(n > 0 && X && y && vec && dinv && ldx >= d, "gpr_lml_grad: bad arguments");
   GPX_TRY(check_mat("gpr_lml_grad: Ky", Ky, ldk, n));
   GPX_REQUIRE(gpx_aligned16(vec) && gpx_aligned16(dinv), "gpr_lml_grad: scratch must be 16-byte aligned");
-  if (grad_host) {
-    GPX_TRY(check_mat("gpr_lml_grad: Kinv", Kinv, ldk, n));
+  if (grad_host)
     for (int k = 0; k < nbeta; ++k) GPX_REQUIRE(b.b[k] > 0.0, "gpr_lml_grad: beta[%d] must be positive", k);
-    GPX_REQUIRE((size_t)n * ldk >= gpx_trtri_work_elems(n), "gpr_lml_grad: Kinv too small for trtri scratch");
-  }
   DeviceGuard dg(h);
   hipStream_t s = h->stream;
   // Ky = K + noise I (lower), regression.py:47-48,58-59
@@ -615,13 +627,14 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
   if (alpha_out) GPX_HIP(hipMemcpyAsync(alpha_out, al_vec, n * sizeof(double), hipMemcpyDeviceToDevice, s));
   int nfetch = 2;
   if (grad_host) {
-    // Ky^-1 = L^-T L^-1 (regression.py:60) and the traces of regression.py:62-72
-    GPX_TRY(trtri_rec(s, n, Ky, ldk, dinv, Kinv));
-    GemmDesc g = mk(Ky, ldk, GPX_LAY_RC, Ky, ldk, GPX_LAY_RC, nullptr, 0, Kinv, ldk, n, n, n, 1.0, 0.0);
-    g.a_tri = g.b_tri = g.c_lower = 1;
-    GPX_TRY(gpx_gemm_launch(s, g));
-    GPX_TRY(gpx_grad_trace_launch(s, X, ldx, d, nbeta, sigma, b, al_vec, Kinv, ldk, 0, 0, n, n, h->red, RED_USABLE,
-                                  sc + 2));
+    // Ky^-1 = L^-T L^-1 (regression.py:60) and the traces of regression.py:62-72, all inside the one buffer:
+    // W = L^-1 replaces L in the lower triangle, Ky^-1 = W^T W goes into the strict upper triangle (its
+    // diagonal into vec[4n, 5n)), and the traces read it from there
+    double* kdiag = vec + 4L * n;
+    GPX_TRY(trtri_rec(s, n, Ky, ldk, dinv));
+    GPX_TRY(lauum_upper(s, n, Ky, ldk, kdiag));
+    GPX_TRY(gpx_grad_trace_launch(s, X, ldx, d, nbeta, sigma, b, al_vec, Ky, ldk, 0, 0, n, n, h->red, RED_USABLE,
+                                  sc + 2, kdiag));
     nfetch = 4 + nbeta;
   }
   double host[GPX_MAXD + 8];

@@ -59,6 +59,10 @@ struct GemmDesc {
   int M, N, K;
   double alpha, beta;
   int c_lower;       // write only row >= col (D starts on the diagonal)
+  int c_upper = 0;   // with c_lower = 1 (tile enumeration) and a SYMMETRIC product: write the mirror image instead --
+                     // D[row][col] for col > row only, the diagonal into diag_out[row]: the strict upper triangle of
+                     // a buffer whose lower triangle holds the (triangular) operands, which are not disturbed
+  double* diag_out = nullptr;
   double diag_add;   // added to D[i][i]
   int inplace;       // GPX_INPLACE_A: D aliases A (N <= 128, row tiles independent); GPX_INPLACE_B: D aliases B
                      // (M <= 128, column tiles independent); one workgroup owns the whole operand panel
@@ -93,7 +97,8 @@ int gpx_gram_dtheta_launch(hipStream_t s, const double* X1, int n1, long ldx1, c
                            double* K, double* dsigma, double* dbeta, long ld, size_t plane);
 int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int nbeta, double sigma,
                           const BetaArg& hb, const double* alpha, const double* Kinv, long ldk, int roff,
-                          int coff, int nr, int nc, double* red, size_t red_elems, double* out_dev);
+                          int coff, int nr, int nc, double* red, size_t red_elems, double* out_dev,
+                          const double* kdiag = nullptr);   // kdiag != nullptr: upper storage (see TraceArgs)
 
 // trsv.hip: x <- L^-1 x (trans 0) / L^-T x (trans 1) for one strided vector
 int gpx_trsv_launch(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv, double* x,

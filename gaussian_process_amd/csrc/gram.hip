@@ -203,6 +203,11 @@ struct TraceArgs {
   const double* X; long ldx; int nr, nc, roff, coff; int d; int nbeta;
   double sigma;
   const double* alpha; const double* Kinv; long ldk;
+  // upper != 0 (full matrix only, roff = coff = 0): Ky^-1 is stored in the STRICT UPPER triangle of the
+  // buffer (element (r, c), c > r, at Kinv[r * ldk + c]) with its diagonal in kdiag -- what
+  // gpx_lauum_upper leaves beside W = L^-1 in one n x n buffer.  The matrix is symmetric, so the sums are
+  // the same; only the tile tests are mirrored.
+  int upper; const double* kdiag;
   double* partials;  // [nblocks][nacc]
   BetaArg sb;        // sqrt(beta_k)
 };
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int bid = blockIdx.y * gridDim.x + blockIdx.x;
   const int rows_here = min(SUBS * GT_ROWS, a.nr - rb);
-  // every sub-tile strictly above the diagonal: nothing to add
-  const bool skip = rows_here <= 0 || a.coff + c0 > a.roff + rb + rows_here - 1;
+  // every sub-tile on the unused side of the diagonal: nothing to add
+  const bool skip = rows_here <= 0 || (a.upper ? c0 + GT_COLS - 1 < rb : a.coff + c0 > a.roff + rb + rows_here - 1);
 
   // acc[0]: sum A_ii (diag)   acc[1]: sum w A_ij K_ij   acc[2+k]: sum w A_ij K_ij z-diff_k^2
   double acc[2 + DD];
@@ -261,11 +266,12 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
     for (int sub = 0; sub < SUBS; ++sub) {
       const int r0 = rb + sub * GT_ROWS;
       if (r0 >= a.nr) break;
-      if (a.coff + c0 > a.roff + r0 + GT_ROWS - 1) continue;   // tile strictly above the diagonal
+      if (a.upper ? c0 + GT_COLS - 1 < r0 : a.coff + c0 > a.roff + r0 + GT_ROWS - 1) continue;   // tile on the unused side
       const double* xs = sx1 + sub * GT_ROWS * d;
       const double* as = sal + sub * GT_ROWS;
-      // interior: whole tile strictly below the diagonal and inside the slab -> weight 2, no predicates
-      const bool interior = a.roff + r0 >= a.coff + c0 + GT_COLS && r0 + GT_ROWS <= a.nr && c0 + GT_COLS <= a.nc;
+      // interior: whole tile strictly off the diagonal on the stored side and inside the slab -> weight 2, no predicates
+      const bool interior = (a.upper ? c0 >= r0 + GT_ROWS : a.roff + r0 >= a.coff + c0 + GT_COLS) &&
+                            r0 + GT_ROWS <= a.nr && c0 + GT_COLS <= a.nc;
       if (interior) {
         const double* src = a.Kinv + (long)(r0 + wid * 16) * a.ldk + c;
 #pragma unroll 2
@@ -305,16 +311,18 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
         const int lr = r0 + r;
         if (lr >= a.nr) break;
         const int gr = a.roff + lr;
-        if (gc > gr || c >= a.nc) continue;  // both columns above the diagonal / outside the slab
+        // which of the lane's two columns lie on the stored side of (or on) the diagonal, inside the slab
+        const bool v0 = c < a.nc && (a.upper ? gc >= gr : gc <= gr);
+        const bool v1 = c + 1 < a.nc && (a.upper ? gc + 1 >= gr : gc + 1 <= gr);
+        if (!v0 && !v1) continue;
         const double* src = a.Kinv + (long)lr * a.ldk + c;
         double q0 = 0.0, q1 = 0.0;
-        const bool v1 = (gc + 1 <= gr) && (c + 1 < a.nc);
-        if (v1) {
-          const v2d q = *reinterpret_cast<const v2d*>(src);
-          q0 = q[0];
-          q1 = q[1];
+        if (a.upper) {          // diagonal entries come from kdiag, the others from the strict upper triangle
+          if (v0) q0 = gc == gr ? a.kdiag[gr] : src[0];
+          if (v1) q1 = gc + 1 == gr ? a.kdiag[gr] : src[1];
         } else {
-          q0 = src[0];
+          if (v0) q0 = src[0];
+          if (v1) q1 = src[1];
         }
         const double ai = as[r];
         double s0 = 0.0, s1 = 0.0;
@@ -330,11 +338,11 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
             s1 += e1[k];
           }
         }
-        const double A0 = ai * al0 - q0;
+        const double A0 = v0 ? ai * al0 - q0 : 0.0;
         const double A1 = v1 ? ai * al1 - q1 : 0.0;
-        const double w0 = (gc == gr ? 1.0 : 2.0) * A0 * exp_nonpos(-0.5 * s0);
+        const double w0 = v0 ? (gc == gr ? 1.0 : 2.0) * A0 * exp_nonpos(-0.5 * s0) : 0.0;
         const double w1 = v1 ? (gc + 1 == gr ? 1.0 : 2.0) * A1 * exp_nonpos(-0.5 * s1) : 0.0;
-        if (gc == gr) acc[0] += A0;
+        if (v0 && gc == gr) acc[0] += A0;
         if (v1 && gc + 1 == gr) acc[0] += A1;
         acc[1] += w0 + w1;
         if (a.nbeta == 1) {
@@ -424,8 +432,10 @@ int gpx_gram_dtheta_launch(hipStream_t s, const double* X1, int n1, long ldx1, c
 
 int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int nbeta, double sigma,
                           const BetaArg& hb, const double* alpha, const double* Kinv, long ldk, int roff,
-                          int coff, int nr, int nc, double* red, size_t red_elems, double* out_dev) {
+                          int coff, int nr, int nc, double* red, size_t red_elems, double* out_dev,
+                          const double* kdiag) {
   TraceArgs a;
+  a.upper = kdiag != nullptr; a.kdiag = kdiag;
   a.X = X; a.ldx = ldx; a.nr = nr; a.nc = nc; a.roff = roff; a.coff = coff; a.d = d; a.nbeta = nbeta;
   a.sigma = sigma; a.alpha = alpha; a.Kinv = Kinv; a.ldk = ldk; a.partials = red;
   for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(hb.b[k]) : 0.0;

@@ -14,10 +14,11 @@ import numpy as np
 from sklearn.utils import check_random_state
 
 from . import _lib
-from .device import ptr, runtime
+from .device import on_device, ptr, runtime
 from .kernels import RBF
 
 
+@on_device
 def generate_gp(n_samples=50, n_features=1, noise=0.01, range=(-3, 3),
                 kernel=RBF(sigma=1.0, beta=1.0), random_state=None, return_latent=False):
     generator = check_random_state(random_state)

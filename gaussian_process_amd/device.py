@@ -31,10 +31,24 @@ class Runtime:
         h = C.c_void_p()
         _lib.check(self.lib.gpx_create(C.byref(h), index), "gpx_create")
         self.h = h
+        # A gpx handle is single-threaded and single-stream (one reduction scratch, one pinned staging
+        # buffer, one stream binding): every estimator operation holds this lock from bind_stream() to its
+        # last fetch (see on_device below).
+        self.lock = threading.RLock()
+        self._stream = None
 
     def bind_stream(self):
-        s = self.torch.cuda.current_stream(self.dev).cuda_stream
-        _lib.check(self.lib.gpx_set_stream(self.h, C.c_void_p(s)), "gpx_set_stream")
+        """Bind the handle to torch's current stream.  When the stream changes, the new one first waits
+        for everything the old one was given: the handle's scratch buffers are shared, so work on two
+        streams must not overlap."""
+        cur = self.torch.cuda.current_stream(self.dev)
+        old = self._stream
+        if old is not None and old.cuda_stream != cur.cuda_stream:
+            ev = self.torch.cuda.Event()
+            ev.record(old)
+            cur.wait_event(ev)
+        self._stream = cur
+        _lib.check(self.lib.gpx_set_stream(self.h, C.c_void_p(cur.cuda_stream)), "gpx_set_stream")
 
     # ---- buffers -------------------------------------------------------------------
     def matrix(self, rows, cols):
@@ -77,6 +91,21 @@ def runtime(index=None):
             rt = Runtime(index)
             _runtimes[index] = rt
     return rt
+
+
+def on_device(fn):
+    """Decorator of the estimator methods that talk to libgpx: one such operation at a time per GPU
+    (threads, e.g. joblib's threading backend, are serialised; the lock is re-entrant for nested calls),
+    with the handle bound to the caller's current torch stream."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        rt = runtime()
+        with rt.lock:
+            rt.bind_stream()
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def ptr(t):

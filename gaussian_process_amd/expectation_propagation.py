@@ -25,7 +25,7 @@ from sklearn.utils import check_X_y
 
 from . import _lib
 from .base import BayesEstimator
-from .device import ptr, runtime
+from .device import on_device, ptr, runtime
 
 eps = 1e-8
 _HALF_LOG_2PI = 0.5 * np.log(2.0 * np.pi)
@@ -49,6 +49,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         self.fit(self.Xtr, self.ytr)
 
     # ------------------------------------------------------------------ device helpers
+    @on_device
     def _recompute(self, dv):
         """L = chol(I + S K S), V = L^-1 S K, Sigma = K - V^T V, mu = Sigma nu on the GPU, from the
         tau / nu vectors resident on the device."""
@@ -60,6 +61,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
                                      ptr(dv["s"]), ptr(dv["mu"]))
         _lib.check(rc, "gpx_ep_recompute")
 
+    @on_device
     def _sweep(self, dv, order):
         """One pass over the sites in `order` (expectation_propagation.py:72-88) on the device."""
         rt = dv["rt"]
@@ -68,6 +70,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
                                        ptr(dv["tau"]), ptr(dv["nu"]), order.ctypes.data_as(C.POINTER(C.c_int)),
                                        len(order), ptr(dv["work"])), "gpx_ep_sweep")
 
+    @on_device
     def _solve_vec(self, dv, rhs, trans):
         """L^-1 rhs (trans=0) or L^-T rhs (trans=1) for a host vector, on the GPU."""
         rt = dv["rt"]
@@ -79,6 +82,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
                                    ptr(buf), 2), "gpx_trsm")
         return rt.download(buf[:, 0]).copy()
 
+    @on_device
     def _solve_mat(self, dv, rhs):
         """L^-1 rhs for a host matrix (n x m)."""
         rt = dv["rt"]
@@ -91,6 +95,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         return buf
 
     # ------------------------------------------------------------------ EP
+    @on_device
     def _ep(self, K, fix_index=None, nu_fixed=None, tau_fixed=None, shuffle=True):
         if fix_index is not None:
             fix_index = np.array(fix_index, dtype=int)
@@ -147,6 +152,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         w = self._solve_vec(dv, self.S.ravel() * self._K_times(nu), trans=0)
         self.z = self.S.ravel() * self._solve_vec(dv, w, trans=1)
 
+    @on_device
     def _K_times(self, v):
         """K v on the device (K resident since the fit)."""
         dv = self._dv
@@ -156,6 +162,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         _lib.check(rt.lib.gpx_gemv(rt.h, 0, n, n, ptr(dv["K"]), dv["K"].shape[1], ptr(x), ptr(out)), "gpx_gemv")
         return rt.download(out[:n]).copy()
 
+    @on_device
     def _diag_Sigma(self):
         dv = self._dv
         rt, n = dv["rt"], dv["n"]
@@ -187,6 +194,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
             self._L_host = np.tril(dv["rt"].download(dv["B"][: dv["n"], : dv["n"]]))
         return self._L_host
 
+    @on_device
     def _cross_cov(self, X):
         """K(Xtr, X) on the host; without the derivative planes when the kernel can skip them."""
         if hasattr(self.cov, "gram_only"):
@@ -198,6 +206,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         Kss = self.cov(X, diag=True).K
         return self._posterior(Ks, Kss)
 
+    @on_device
     def _posterior(self, Ks, Kss):
         mean = Ks.T @ (self.nu_tilde - self.z)
         dv = self._dv
@@ -211,6 +220,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
     def predict(self, X):
         return np.sign(self.decision_function(X) - 0.5)
 
+    @on_device
     def log_marginal_likelihood(self, splitted_terms=False):
         dS = self._diag_Sigma()
         tau_cav = 1 / dS - self.tau_tilde
@@ -234,6 +244,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         terms = (t0, t1, t2, t3, t4, t5, t6)
         return terms if splitted_terms else sum(terms)
 
+    @on_device
     def grad_log_marginal_likelihood(self, splitted_terms=False):
         """expectation_propagation.py:152-167.  For the stationary kernels of this package everything stays
         on the device: U = L^-1 diag(S) (TRSM), U^T U (MFMA GEMM), b = nu - U^T U K nu (two GEMVs) and
@@ -265,7 +276,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         def traces(alpha_d, M):
             out = (C.c_double * ng)()
             _lib.check(lib.gpx_grad_trace(rt.h, kind, ptr(dX), n, dX.shape[1], self.dim, sigma, beta_p, ptr(alpha_d),
-                                          ptr(M), M.shape[1], C.cast(out, C.POINTER(C.c_double))), "gpx_grad_trace")
+                                          ptr(M), M.shape[1], None, C.cast(out, C.POINTER(C.c_double))), "gpx_grad_trace")
             return np.array(list(out))
 
         # 1/2 sum (b b^T) o dK: the trace kernel with a zero matrix in place of Ky^-1 (dv["V"] is free after the fit)
@@ -279,6 +290,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         out = {"cov__sigma": pair(1), "cov__beta": cov_beta}
         return {k: v if splitted_terms else np.sum(v) for k, v in out.items()}
 
+    @on_device
     def _UtU_device(self, dv):
         """U^T U for U = L^-1 diag(S) (expectation_propagation.py:162) as a device matrix (full, symmetric)."""
         rt, n = dv["rt"], dv["n"]
@@ -293,6 +305,7 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
                                    ptr(UtU), UtU.shape[1]), "gpx_gemm")
         return UtU
 
+    @on_device
     def _grad_log_marginal_likelihood(self, K, K_grads):
         """expectation_propagation.py:161-167 for arbitrary host derivative matrices (Distillation's Kronecker
         planes): U^T U on the device, the contractions with the caller's planes on the host."""

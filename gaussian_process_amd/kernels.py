@@ -19,7 +19,7 @@ import numpy as np
 from sklearn.base import BaseEstimator
 
 from . import _lib
-from .device import ptr, runtime
+from .device import on_device, ptr, runtime
 
 KernelValue = namedtuple("KernelValue", ["K", "dtheta"])
 
@@ -44,6 +44,7 @@ class _StationaryKernel(BaseEstimator):
         """(kind id, sigma, beta array) as the C ABI wants them."""
         return _lib.GPX_KIND[self.kind], float(self.sigma), self._beta_vector(dim)
 
+    @on_device
     def _evaluate(self, X1, X2, want_dtheta=True):
         rt = runtime()
         rt.bind_stream()
@@ -77,6 +78,7 @@ class _StationaryKernel(BaseEstimator):
         assert X1.shape[1] == X2.shape[1], "X1 and X2 must have the same number of features"
         return self._evaluate(X1, X2, want_dtheta=False)[0]
 
+    @on_device
     def device_gram(self, X, diag_add=0.0):
         """K(X, X) + diag_add * I as a device-resident matrix (full, symmetric): what the estimators use
         when the host copy that ``__call__`` returns is not needed.  Same argument checks as

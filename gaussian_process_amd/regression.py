@@ -23,7 +23,7 @@ from sklearn.utils import check_X_y
 
 from . import _lib
 from .base import BayesEstimator
-from .device import ptr, runtime
+from .device import on_device, ptr, runtime
 
 
 class GaussianProcessRegression(RegressorMixin, BayesEstimator):
@@ -64,10 +64,11 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
             rt = runtime()
             n = self.n
             self._dev = dict(rt=rt, X=rt.upload_matrix(self.Xtr), y=rt.upload_vector(self.ytr),
-                             Ky=rt.matrix(n, n), Kinv=None, dinv=rt.dinv(n), vec=rt.vector(4 * n),
+                             Ky=rt.matrix(n, n), dinv=rt.dinv(n), vec=rt.vector(5 * n),
                              alpha=rt.vector(n), a=rt.vector(n))
         return self._dev
 
+    @on_device
     def _evaluate(self, need_grad):
         """One fused evaluation at the current theta; cached until theta or the data change."""
         key = self._theta_key()
@@ -78,8 +79,6 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         rt = dv["rt"]
         rt.bind_stream()
         n = self.n
-        if need_grad and dv["Kinv"] is None:
-            dv["Kinv"] = rt.matrix(n, n)
         kind, sigma_k, beta = key[0], key[1], np.array(key[2])
         # the call overwrites the resident factor: whatever was cached is gone from here on, also if
         # the call raises (LinAlgError at a non-PD trial theta of L-BFGS-B)
@@ -91,7 +90,7 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         ld = dv["Ky"].shape[1]
         rc = rt.lib.gpx_gpr_lml_grad(
             rt.h, kind, ptr(dv["X"]), n, dv["X"].shape[1], self.dim, sigma_k, beta_p, key[3],
-            ptr(dv["y"]), ptr(dv["Ky"]), ptr(dv["Kinv"]) if need_grad else None, ld, ptr(dv["dinv"]),
+            ptr(dv["y"]), ptr(dv["Ky"]), ld, ptr(dv["dinv"]),
             ptr(dv["vec"]), ptr(dv["alpha"]), ptr(dv["a"]), C.byref(lml),
             C.cast(grad, C.POINTER(C.c_double)) if need_grad else None)
         _lib.check(rc, "gpx_gpr_lml_grad")
@@ -109,6 +108,7 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         g = self._evaluate(need_grad=True)["grad"]
         return {"sigma": np.array([g[0]]), "cov__sigma": np.array([g[1]]), "cov__beta": g[2:].copy()}
 
+    @on_device
     def alpha_(self):
         """alpha = Ky^-1 y (regression.py:61) of the cached evaluation, as a NumPy array."""
         self._evaluate(need_grad=False)
@@ -121,6 +121,7 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         the device in batches."""
         return self.predict_with_variance(X, full_cov=False)[0]
 
+    @on_device
     def predict_with_variance(self, X, full_cov=True, batch=16384):
         """(mean (m,), cov (m, m)) as regression.py:31-44; ``full_cov=False`` returns the
         diagonal variance (m,) instead, never forms the m x m matrix and tiles over the test points

@@ -58,8 +58,6 @@ const char* gpx_last_error(void);
 const char* gpx_version(void);
 /* Number of doubles the caller must provide for `dinv` given n (ceil(n/128) blocks of 128x128). */
 size_t gpx_dinv_elems(int n);
-/* Number of doubles of scratch gpx_trtri / gpx_potri need for order n. */
-size_t gpx_trtri_work_elems(int n);
 
 /* ---- Gram matrix and derivatives ------------------------------------------------------ */
 /* K[i][j] = sigma * exp(-0.5 * sum_k beta_k (X1[i][k]-X2[j][k])^2) (+ diag_add if i==j).
@@ -101,11 +99,18 @@ int gpx_trsm(gpx_handle* h, int trans, int n, int nrhs, const double* L, int ldl
              const double* dinv, double* B, int ldb);
 /* out_host[0] = sum_i log L[i][i]   (regression.py:53, expectation_propagation.py:133). */
 int gpx_logdet(gpx_handle* h, int n, const double* L, int ldl, double* out_host);
-/* L <- L^-1 in place (lower).  work: gpx_trtri_work_elems(n) doubles. */
-int gpx_trtri(gpx_handle* h, int n, double* L, int ldl, const double* dinv, double* work);
+/* L <- L^-1 in place (lower).  Needs no workspace: the blocks of L's own n x ldl buffer that lie strictly
+ * above the 128 x 128 diagonal blocks serve as scratch and hold garbage on exit (no lower-triangular
+ * consumer reads them). */
+int gpx_trtri(gpx_handle* h, int n, double* L, int ldl, const double* dinv);
 /* Kinv(lower) = W^T W for lower-triangular W = L^-1: together with gpx_trtri this is potri and
  * replaces scipy.linalg.inv(Ky) at regression.py:60 (SPD route instead of LU). */
 int gpx_lauum(gpx_handle* h, int n, const double* W, int ldw, double* Kinv, int ldk);
+/* The same product kept in W's own buffer: Ky^-1[i][j], i < j, goes to W[i * ldw + j] (the strict upper
+ * triangle, also inside the diagonal blocks) and its diagonal to kdiag (n doubles); the lower triangle
+ * (W itself) is not disturbed.  With gpx_trtri: factor, inverse factor and inverse in ONE n x n buffer
+ * (regression.py:60 in half the memory).  gpx_grad_trace reads this storage when given kdiag. */
+int gpx_lauum_upper(gpx_handle* h, int n, double* W, int ldw, double* kdiag);
 /* C(m x m) <- C - V^T V + diag_add * I, V is n x m.  uplo GPX_FULL or GPX_LOWER.
  * Replaces regression.py:41-44 and `K - V.T @ V` at expectation_propagation.py:64,93. */
 int gpx_syrk_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double* C, int ldc,
@@ -151,11 +156,13 @@ int gpx_diag(gpx_handle* h, int n, const double* A, int lda, double* diag_out);
 /* out_host[0]      = 0.5 * tr(A)                      d/d(noise)      regression.py:63,70
  * out_host[1]      = 0.5 * sum_ij A_ij K_ij / sigma   d/d(cov sigma)  kernels.py:39,81
  * out_host[2 + p]  = 0.5 * sum_ij A_ij (-0.5 diff_p K_ij), p < (ARD ? d : 1)   kernels.py:38,80
- * with A = alpha alpha^T - Kinv (regression.py:62), Kinv given in its LOWER triangle and K,
- * diff recomputed from X on the fly: the (d,n,n) tensor of kernels.py:80 never exists. */
+ * with A = alpha alpha^T - Kinv (regression.py:62) and K, diff recomputed from X on the fly: the (d,n,n)
+ * tensor of kernels.py:80 never exists.  Kinv storage: kdiag == NULL -- the LOWER triangle of Kinv (what
+ * gpx_lauum writes); kdiag != NULL -- the STRICT UPPER triangle of Kinv plus the diagonal in kdiag (what
+ * gpx_lauum_upper writes). */
 int gpx_grad_trace(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
                    const double* beta_host, const double* alpha, const double* Kinv, int ldk,
-                   double* out_host);
+                   const double* kdiag, double* out_host);
 /* The same sums restricted to a slab of the symmetric matrix: Kinv_slab holds rows
  * [row_off, row_off+nrows) x columns [col_off, col_off+ncols) of Ky^-1 (only its entries on or below
  * the global diagonal are read).  The slabs of a partition of the lower triangle add up to
@@ -166,15 +173,17 @@ int gpx_grad_trace_slab(gpx_handle* h, int kind, const double* X, int n, int ldx
                         int row_off, int col_off, int nrows, int ncols, double* out_host);
 
 /* ---- fused estimator paths ------------------------------------------------------------ */
-/* One evaluation of (LML, grad) = regression.py:46-76 from one Gram + one factorisation:
- *   Ky (n x ldk, overwritten: L^-1 on exit), Kinv (n x ldk, Ky^-1 lower on exit),
- *   dinv (gpx_dinv_elems(n)), vec (4*n doubles of scratch).
+/* One evaluation of (LML, grad) = regression.py:46-76 from one Gram + one factorisation in ONE n x n
+ * buffer:
+ *   Ky (n x ldk, overwritten): with the gradient, L^-1 in the lower triangle and Ky^-1 in the strict upper
+ *   triangle on exit (its diagonal in vec[4n, 5n)); without, L in the lower triangle.
+ *   dinv (gpx_dinv_elems(n)), vec (5*n doubles of scratch).
  *   alpha_out (n) = Ky^-1 y, a_out (n) = L^-1 y (either may be NULL).
- *   lml_host[0] = LML; grad_host[0..1+nb] as gpx_grad_trace (NULL = skip the gradient, in
- *   which case Ky holds L on exit and Kinv is not touched). */
+ *   lml_host[0] = LML; grad_host[0..1+nb] as gpx_grad_trace (NULL = skip the gradient).
+ * Returns LAPACK info > 0 right after the factorisation if Ky is not positive definite. */
 int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, int d,
                      double sigma, const double* beta_host, double noise, const double* y,
-                     double* Ky, double* Kinv, int ldk, double* dinv, double* vec,
+                     double* Ky, int ldk, double* dinv, double* vec,
                      double* alpha_out, double* a_out, double* lml_host, double* grad_host);
 /* regression.py:31-44 given the factor L (lower) of Ky and its dinv:
  *   V (n x ldv >= m) scratch, mean (m), cov (m x ldc) = K(Xs,Xs) - V^T V + noise I (full matrix,

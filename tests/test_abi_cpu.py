@@ -33,7 +33,6 @@ def test_sizes_without_gpu():
     assert lib.gpx_dinv_elems(1) == 128 * 128
     assert lib.gpx_dinv_elems(129) == 2 * 128 * 128
     assert lib.gpx_dinv_elems(65536) == 512 * 128 * 128
-    assert lib.gpx_trtri_work_elems(65536) == 32768 * 32768
 
 
 def test_parameter_protocol_matches_reference():

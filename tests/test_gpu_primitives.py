@@ -162,8 +162,7 @@ def test_potrf_trsm_trtri_lauum(rt, n):
             ref = sla.solve_triangular(Lref, B, lower=True, trans="T" if trans else "N")
             assert relerr(down(rt, dB, n, nrhs), ref) < 1e-12
     # potri = trtri + lauum
-    work = rt.vector(int(rt.lib.gpx_trtri_work_elems(n)))
-    ok(rt.lib.gpx_trtri(rt.h, n, P(dA), ld, P(dinv), P(work)))
+    ok(rt.lib.gpx_trtri(rt.h, n, P(dA), ld, P(dinv)))      # scratch: the blocks above the diagonal blocks
     W = np.tril(down(rt, dA, n, n))
     assert relerr(W, np.linalg.inv(Lref)) < 1e-12
     Kinv = rt.matrix(n, n)
@@ -171,6 +170,14 @@ def test_potrf_trsm_trtri_lauum(rt, n):
     assert relerr(np.tril(down(rt, Kinv, n, n)), np.tril(np.linalg.inv(A))) < 1e-12
     ok(rt.lib.gpx_symmetrize(rt.h, n, P(Kinv), Kinv.shape[1]))
     assert relerr(down(rt, Kinv, n, n), np.linalg.inv(A)) < 1e-12
+    # the same product inside W's own buffer: strict upper triangle + diagonal vector, W untouched
+    kd = rt.vector(n)
+    ok(rt.lib.gpx_lauum_upper(rt.h, n, P(dA), ld, P(kd)))
+    both = down(rt, dA, n, n)
+    Ainv = np.linalg.inv(A)
+    assert np.array_equal(np.tril(both), W)
+    assert relerr(np.triu(both, 1), np.triu(Ainv, 1)) < 1e-12
+    assert relerr(rt.download(kd)[:n], np.diag(Ainv)) < 1e-12
 
 
 @pytest.mark.parametrize("n", [100, 257, 513, 1024, 1153, 4097, 9000, 16500])
@@ -285,10 +292,19 @@ def test_grad_trace_matches_oracle(rt, kind, d, n):
     barr, bp = _lib.host_doubles(beta)
     out = (C.c_double * (2 + len(barr)))()
     ok(rt.lib.gpx_grad_trace(rt.h, _lib.GPX_KIND[kind], P(dX), n, dX.shape[1], d, sigma, bp, P(dal),
-                             P(dKi), dKi.shape[1], C.cast(out, C.POINTER(C.c_double))))
+                             P(dKi), dKi.shape[1], None, C.cast(out, C.POINTER(C.c_double))))
     got = np.array(list(out))
     ref = np.concatenate([g_o["sigma"], g_o["cov__sigma"], g_o["cov__beta"]])
     assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+    # upper storage (what gpx_lauum_upper leaves): strict upper triangle + diagonal vector; the lower
+    # triangle of the buffer belongs to W and must never be read -- NaN there must not reach the sums
+    Ku = np.triu(Kinv, 1) + np.tril(np.full((n, n), np.nan))
+    dKu, dkd = up(rt, Ku), rt.upload_vector(np.diag(Kinv).copy())
+    out2 = (C.c_double * (2 + len(barr)))()
+    ok(rt.lib.gpx_grad_trace(rt.h, _lib.GPX_KIND[kind], P(dX), n, dX.shape[1], d, sigma, bp, P(dal),
+                             P(dKu), dKu.shape[1], P(dkd), C.cast(out2, C.POINTER(C.c_double))))
+    got2 = np.array(list(out2))
+    assert np.abs(got2 - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("kind,d,n,cuts", [("ard", 8, 300, [0, 128, 256, 300]), ("rbf", 2, 257, [0, 128, 256, 257]),
@@ -357,7 +373,7 @@ dX, dal, dM = rt.upload_matrix(X), rt.upload_vector(al), rt.upload_matrix(M)
 barr, bp = _lib.host_doubles(beta)
 out = (C.c_double * (2 + d))()
 _lib.check(rt.lib.gpx_grad_trace(rt.h, 1, ptr(dX), n, dX.shape[1], d, 1.3, bp, ptr(dal), ptr(dM), dM.shape[1],
-                                 C.cast(out, C.POINTER(C.c_double))), "grad_trace")
+                                 None, C.cast(out, C.POINTER(C.c_double))), "grad_trace")
 print(" ".join(repr(v) for v in out))
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []

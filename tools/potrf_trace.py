@@ -17,10 +17,10 @@ print("POTRF-BEGIN", file=sys.stderr, flush=True)
 _lib.check(rt.lib.gpx_potrf(rt.h, n, P(K), K.shape[1], P(dinv)), "potrf")
 torch.cuda.synchronize()
 if len(sys.argv) > 2:
-    Kinv = rt.matrix(n, n)
+    kd = rt.vector(n)
     print("PHASE trtri", file=sys.stderr, flush=True)
-    _lib.check(rt.lib.gpx_trtri(rt.h, n, P(K), K.shape[1], P(dinv), P(Kinv)), "trtri")
+    _lib.check(rt.lib.gpx_trtri(rt.h, n, P(K), K.shape[1], P(dinv)), "trtri")
     torch.cuda.synchronize()
     print("PHASE lauum", file=sys.stderr, flush=True)
-    _lib.check(rt.lib.gpx_lauum(rt.h, n, P(K), K.shape[1], P(Kinv), Kinv.shape[1]), "lauum")
+    _lib.check(rt.lib.gpx_lauum_upper(rt.h, n, P(K), K.shape[1], P(kd)), "lauum")
     torch.cuda.synchronize()

@@ -40,7 +40,7 @@ lower_bytes = 4.0 * n * (n + 1)
 t = timed(lambda: rt.lib.gpx_gram(rt.h, 1, ptr(dX), n, dX.shape[1], None, 0, 0, 8, 1.0, bp, 0.1, ptr(A), ld, 1))
 print("gram lower   min %.3f ms avg %.3f ms  %.2f TB/s" % (t[0], t[1], lower_bytes / t[0] / 1e9), flush=True)
 out = (C.c_double * 10)()
-t = timed(lambda: rt.lib.gpx_grad_trace(rt.h, 1, ptr(dX), n, dX.shape[1], 8, 1.0, bp, ptr(dy), ptr(A), ld,
+t = timed(lambda: rt.lib.gpx_grad_trace(rt.h, 1, ptr(dX), n, dX.shape[1], 8, 1.0, bp, ptr(dy), ptr(A), ld, None,
                                         C.cast(out, C.POINTER(C.c_double))))
 print("grad_trace   min %.3f ms avg %.3f ms  %.2f TB/s (incl. final reduction + fetch)" % (t[0], t[1], lower_bytes / t[0] / 1e9), flush=True)
 info = rt.lib.gpx_potrf(rt.h, n, ptr(A), ld, ptr(dinv))
