@@ -763,8 +763,8 @@ int gpx_ep_recompute(gpx_handle* h, int n, const double* K, int ldk, const doubl
   return info;
 }
 
-int gpx_trmm(gpx_handle* h, int n, int m, const double* L, int ldl, const double* B, int ldb, double* Out,
-             int ldo) {
+int gpx_trmm(gpx_handle* h, int trans, int n, int m, const double* L, int ldl, const double* B, int ldb,
+             double* Out, int ldo) {
   GPX_REQUIRE(h != nullptr, "null handle");
   if (n <= 0 || m <= 0) return 0;
   GPX_TRY(check_mat("trmm: L", L, ldl, n));
@@ -772,8 +772,8 @@ int gpx_trmm(gpx_handle* h, int n, int m, const double* L, int ldl, const double
   GPX_TRY(check_mat("trmm: Out", Out, ldo, m));
   GPX_REQUIRE(Out != B, "trmm: Out must not alias B");
   DeviceGuard dg(h);
-  // op(A) = L (stored [i][k], valid k <= i), op(B) = B stored [k][j]
-  GemmDesc g = mk(L, ldl, GPX_LAY_KC, B, ldb, GPX_LAY_RC, nullptr, 0, Out, ldo, n, m, n, 1.0, 0.0);
+  // op(A) = L (stored [i][k], valid k <= i: KC) or L^T (stored [k][i], valid i <= k: RC); op(B) = B stored [k][j]
+  GemmDesc g = mk(L, ldl, trans ? GPX_LAY_RC : GPX_LAY_KC, B, ldb, GPX_LAY_RC, nullptr, 0, Out, ldo, n, m, n, 1.0, 0.0);
   g.a_tri = 1;
   return gpx_gemm_launch(h->stream, g);
 }

@@ -39,7 +39,7 @@ def generate_gp(n_samples=50, n_features=1, noise=0.01, range=(-3, 3),
     dz = rt.torch.zeros((n, 2), dtype=rt.torch.float64, device=rt.dev)
     dz[:, 0].copy_(rt.torch.from_numpy(z))
     out = rt.torch.empty((n, 2), dtype=rt.torch.float64, device=rt.dev)
-    _lib.check(rt.lib.gpx_trmm(rt.h, n, 1, ptr(Ky), ld, ptr(dz), 2, ptr(out), 2), "gpx_trmm")
+    _lib.check(rt.lib.gpx_trmm(rt.h, 0, n, 1, ptr(Ky), ld, ptr(dz), 2, ptr(out), 2), "gpx_trmm")
     y = rt.download(out[:, 0]).copy()
     if return_latent:
         return X, y, z

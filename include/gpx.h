@@ -119,11 +119,13 @@ int gpx_syrk_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double* 
  * transa/transb: 0 = stored as op, 1 = stored transposed. */
 int gpx_gemm(gpx_handle* h, int transa, int transb, int M, int N, int K, double alpha,
              const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc);
-/* Out (n x m) = L B for the lower-triangular n x n factor L (only its lower triangle is read) and
- * B n x m: sampling f = L z from the GP prior / posterior with the factor gpx_potrf produced, the
- * O(n^2) replacement for numpy's SVD-based multivariate_normal at datasets.py:12. */
-int gpx_trmm(gpx_handle* h, int n, int m, const double* L, int ldl, const double* B, int ldb, double* Out,
-             int ldo);
+/* Out (n x m) = L B (trans = 0) or L^T B (trans = 1) for a lower-triangular n x n matrix L (only its
+ * lower triangle is read) and B n x m; Out must not alias B.  Sampling f = L z from the GP prior /
+ * posterior with the factor gpx_potrf produced -- the O(n^2) replacement for numpy's SVD-based
+ * multivariate_normal at datasets.py:12 -- and, with L = W = a tile's explicit inverse (gpx_trtri),
+ * the many-right-hand-side tile solves W B / W^T B of the multi-GPU path (regression.py:38,61). */
+int gpx_trmm(gpx_handle* h, int trans, int n, int m, const double* L, int ldl, const double* B, int ldb,
+             double* Out, int ldo);
 /* y(m) = A^T x for A n x m row-major (trans=1) or y(n) = A x (trans=0); fixed-order reduction.
  * regression.py:39 (mean = a . V), expectation_propagation.py:65,94,116. */
 int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,

@@ -78,6 +78,14 @@ class NumpyOps:
         b = B.numpy()
         b[...] = sla.solve_triangular(l, b, lower=True, trans="T" if trans else "N", check_finite=False)
 
+    def trtri(self, W, dinv):
+        w = W.numpy()
+        w[...] = np.tril(sla.solve_triangular(np.tril(w), np.eye(w.shape[0]), lower=True, check_finite=False))
+
+    def trmm(self, trans, W, B, Out):
+        w = np.tril(W.numpy())
+        Out.numpy()[...] = (w.T if trans else w) @ B.numpy()
+
     def logdet(self, L):
         return float(np.log(np.diagonal(L.numpy())).sum())
 

@@ -56,7 +56,7 @@ def worker(rank, world, port, case, q):
         grid = tuple(case["grid"]) if case.get("grid") else None
         gp = DistributedGP(ops, dist, rank, world, block=block, update_k=case.get("update_k", 2048),
                            grad_block=case.get("grad_block", 256), grid=grid,
-                           force_collectives=bool(case.get("force_collectives")))
+                           force_collectives=bool(case.get("force_collectives")), many_rhs=case.get("many_rhs"))
         out = {"rank": rank}
         if case.get("estimator"):
             # the reference's estimator interface over the ranks (distributed_regression.py)
@@ -191,6 +191,8 @@ def _nccl_world1():
                       update_k=512, grad_block=512),
                  dict(n=1100, m=30, d=3, block=256, kind="ard", gpu=True, backend="nccl", force_collectives=True,
                       update_k=256, grad_block=256),
+                 dict(n=2300, m=70, d=3, block=512, kind="ard", gpu=True, backend="nccl", force_collectives=True,
+                      update_k=512, grad_block=1024, many_rhs=64),
                  dict(n=600, m=21, d=2, block=128, kind="ard", gpu=True, backend="nccl", force_collectives=True,
                       estimator=True)):
         q = Q()

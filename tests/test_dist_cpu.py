@@ -35,6 +35,8 @@ CASES2 = [
     dict(n=1500, m=9, d=2, block=128, kind="ard", update_k=128, grad_block=384),   # no delay; gradient slabs of 3 tiles
     dict(n=1100, m=6, d=3, block=256, kind="ard", grid=(1, 2)),    # 1 x 2: the row broadcast carries the whole panel
     dict(n=900, m=6, d=3, block=128, kind="ard", force_collectives=True),   # 2 x 1 with the one-rank row groups in use
+    # tile solves by the tiles' explicit inverses (many right-hand sides) + gradient slabs of 2 tiles, ragged last tile
+    dict(n=1400, m=70, d=3, block=256, kind="ard", update_k=512, grad_block=512, many_rhs=64),
 ]
 
 
@@ -54,8 +56,9 @@ def test_world3_matches_oracle():
     (4, dict(n=1300, m=10, d=3, block=128, kind="ard", update_k=256, grid=(4, 1))),              # 4 x 1
     (6, dict(n=1500, m=11, d=2, block=128, kind="ard", update_k=256, grad_block=256)),           # 2 x 3: P does not divide Q
     (8, dict(n=2200, m=12, d=2, block=128, kind="ard", update_k=256, grad_block=512)),           # 2 x 4, 18 tiles
+    (4, dict(n=2100, m=80, d=3, block=256, kind="ard", update_k=512, grad_block=768, many_rhs=64)),   # 2 x 2, inverse-tile solves, slabs of 3 tiles
     (8, dict(n=1800, m=12, d=2, block=128, kind="ard", update_k=384, grad_block=256, grid=(4, 2))),   # 4 x 2
-], ids=["world4_2x2", "world4_4x1", "world6_2x3", "world8_2x4", "world8_4x2"])
+], ids=["world4_2x2", "world4_4x1", "world6_2x3", "world8_2x4", "world4_2x2_tile_inverses", "world8_4x2"])
 def test_more_ranks_match_oracle(world, case):
     _check(_run(world, case), case, world)
 

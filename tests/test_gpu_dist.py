@@ -22,6 +22,8 @@ CASES = [
     dict(n=100, m=5, d=2, block=128, kind="ard", gpu=True),       # one tile: rank 1 owns nothing
     dict(n=3000, m=17, d=8, block=128, kind="ard", gpu=True, update_k=512, grad_block=512),   # delayed updates, groups of 4
     dict(n=3000, m=17, d=8, block=256, kind="ard", gpu=True, update_k=256, grid=(1, 2)),      # 1 x 2 grid
+    # tile solves by the tiles' explicit inverses (gpx_trtri + gpx_trmm), gradient slabs of 2 tiles, ragged tiles
+    dict(n=2900, m=90, d=8, block=512, kind="ard", gpu=True, update_k=512, grad_block=1024, many_rhs=64),
 ]
 
 

@@ -339,16 +339,18 @@ def test_grad_trace_slabs_add_up(rt, kind, d, n, cuts):
                                       C.cast(out, C.POINTER(C.c_double))) == -1
 
 
-@pytest.mark.parametrize("n,m", [(1, 1), (130, 3), (700, 64), (1025, 1)])
+@pytest.mark.parametrize("n,m", [(1, 1), (130, 3), (700, 64), (1025, 1), (2048, 700)])
 def test_trmm_lower_times_matrix(rt, n, m):
-    """Out = L B reading only the lower triangle of L (garbage above it must not matter)."""
+    """Out = L B and Out = L^T B reading only the lower triangle of L (garbage above it must not matter)."""
     rng = np.random.default_rng(n + m)
     L = np.tril(rng.standard_normal((n, n)))
     B = rng.standard_normal((n, m))
     dL = up(rt, L + np.triu(np.full((n, n), np.nan), 1))     # NaN above the diagonal
     dB, dO = up(rt, B), rt.matrix(n, m)
-    ok(rt.lib.gpx_trmm(rt.h, n, m, P(dL), dL.shape[1], P(dB), dB.shape[1], P(dO), dO.shape[1]))
+    ok(rt.lib.gpx_trmm(rt.h, 0, n, m, P(dL), dL.shape[1], P(dB), dB.shape[1], P(dO), dO.shape[1]))
     assert relerr(down(rt, dO, n, m), L @ B) < 1e-13
+    ok(rt.lib.gpx_trmm(rt.h, 1, n, m, P(dL), dL.shape[1], P(dB), dB.shape[1], P(dO), dO.shape[1]))
+    assert relerr(down(rt, dO, n, m), L.T @ B) < 1e-13
 
 
 def test_grad_trace_row_bands_give_the_same_sums():
