@@ -58,6 +58,29 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return ldexp(p, (int)kf);
 }
 
+// exp for the Gram kernel proper: K = sigma * exp(-h), h = 0.5 * sum_k beta_k (x_k - x'_k)^2 >= 0 handed
+// over already halved (the coordinates are pre-scaled by sqrt(beta_k / 2)).  Table-driven: with
+// kf = rint(-h * 64 / ln 2) = 64 e + j,  exp(-h) = 2^e * 2^(j/64) * exp(r),  |r| <= ln 2 / 128, so a
+// degree-5 Taylor polynomial suffices (truncation r^6 / 720 < 4e-17) and sigma * 2^(j/64) comes from a
+// 64-entry table in LDS (one ds_read per element).  15 VALU instructions per element against 24 for
+// exp_nonpos + scaling: at d = 8 the kernel was bound by its fp64 VALU work (40 instructions per
+// element), not by the stores.  Error < 1.5 ulp; underflows gradually through v_ldexp_f64.
+constexpr int EXP_TAB = 64;
+
+__device__ __forceinline__ double exp_neg_tab(double h, const double* tab) {
+  const double kf = rint(h * -9.23324826168936574e+01);            // -64 / ln 2
+  double r = fma(kf, -1.0830417275428772e-02, -h);                 // r = -h - kf * ln2/64: hi part (32 trailing zero bits: kf * hi is exact)
+  r = fma(kf, -7.420820373486988e-09, r);                          // lo part
+  const int ki = (int)kf;
+  const double tj = tab[ki & (EXP_TAB - 1)];                       // sigma * 2^(j/64)
+  double p = horner(8.3333333333333332e-03, r, 4.1666666666666664e-02);   // 1/5!, 1/4!
+  p = horner(p, r, 1.6666666666666666e-01);                        // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p * tj, ki >> 6);
+}
+
 struct GramArgs {
   const double* X1; long ldx1; int n1;
   const double* X2; long ldx2; int n2;
@@ -65,33 +88,43 @@ struct GramArgs {
   double sigma, diag_add;
   double* K; long ldk;
   int lower;
-  BetaArg sb;  // sqrt(beta_k)
+  BetaArg sb;  // sqrt(beta_k / 2)
+  double tab[EXP_TAB];  // sigma * 2^(j/64)
 };
 
 // D > 0: compile-time dimension (unrolled, registers); D == 0: runtime d <= GPX_MAXD.
-template <int D>
+// CP: column pairs per lane.  A workgroup owns GT_SUBS row sub-tiles (64 rows each) of one strip of
+// 128 * CP columns; lane l holds columns c0 + 128 q + 2 l, + 1 for q < CP, so every store instruction
+// of a wave still writes 1 KiB of one row and a wave writes CP KiB of each row back to back.  CP = 4
+// (512-column strips) for the compiled dimensions: the store pattern sustains 6.1 TB/s against 5.6
+// for 128-column strips (tools/store_pattern.hip), and a row of X1 read from LDS serves 8 elements.
+template <int D, int CP>
 __global__ __launch_bounds__(GT_THREADS) void gram_kernel(const GramArgs a) {
-  // One workgroup owns GT_SUBS row sub-tiles (64 rows each) of one 128-column strip: the per-lane
-  // X2 rows (registers) and one LDS fill serve 256 KiB of output, so the prologue's load latency
-  // is paid once per four tiles.
-  __shared__ double sx1[GT_SUBS * GT_ROWS * (D > 0 ? D : GPX_MAXD)];
+  constexpr int DD = D > 0 ? D : GPX_MAXD;
+  constexpr int COLS = GT_COLS * CP;
+  __shared__ double sx1[GT_SUBS * GT_ROWS * DD];
+  __shared__ double stab[EXP_TAB];
   const int d = D > 0 ? D : a.d;
-  const int rb = blockIdx.y * (GT_SUBS * GT_ROWS), c0 = blockIdx.x * GT_COLS;
+  const int rb = blockIdx.y * (GT_SUBS * GT_ROWS), c0 = blockIdx.x * COLS;
   if (a.lower && c0 > rb + GT_SUBS * GT_ROWS - 1) return;  // every sub-tile strictly above the diagonal
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  if (t < EXP_TAB) stab[t] = a.tab[t];
 
   for (int e = t; e < GT_SUBS * GT_ROWS * d; e += GT_THREADS) {
     const int r = e / d, k = e - r * d;
     const int gr = rb + r;
     sx1[e] = gr < a.n1 ? a.X1[(long)gr * a.ldx1 + k] * a.sb.b[k] : 0.0;
   }
-  const int c = c0 + 2 * lane;
-  double z0[D > 0 ? D : GPX_MAXD], z1[D > 0 ? D : GPX_MAXD];
+  double z[CP][2][DD];
 #pragma unroll
-  for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
-    if (k < d) {
-      z0[k] = c < a.n2 ? a.X2[(long)c * a.ldx2 + k] * a.sb.b[k] : 0.0;
-      z1[k] = c + 1 < a.n2 ? a.X2[(long)(c + 1) * a.ldx2 + k] * a.sb.b[k] : 0.0;
+  for (int q = 0; q < CP; ++q) {
+    const int c = c0 + q * GT_COLS + 2 * lane;
+#pragma unroll
+    for (int k = 0; k < DD; ++k) {
+      if (k < d) {
+        z[q][0][k] = c < a.n2 ? a.X2[(long)c * a.ldx2 + k] * a.sb.b[k] : 0.0;
+        z[q][1][k] = c + 1 < a.n2 ? a.X2[(long)(c + 1) * a.ldx2 + k] * a.sb.b[k] : 0.0;
+      }
     }
   }
   __syncthreads();
@@ -102,27 +135,31 @@ __global__ __launch_bounds__(GT_THREADS) void gram_kernel(const GramArgs a) {
     if (a.lower && c0 > r0 + GT_ROWS - 1) continue;  // tile strictly above the diagonal: not touched
     const double* xs = sx1 + sub * GT_ROWS * d;
     // interior tiles (no matrix edge, no diagonal inside): no selects, no bounds tests
-    const bool touches_diag = c0 < r0 + GT_ROWS && r0 < c0 + GT_COLS;
-    const bool interior = r0 + GT_ROWS <= a.n1 && c0 + GT_COLS <= a.n2 &&
+    const bool touches_diag = c0 < r0 + GT_ROWS && r0 < c0 + COLS;
+    const bool interior = r0 + GT_ROWS <= a.n1 && c0 + COLS <= a.n2 &&
                           !(touches_diag && (a.lower || a.diag_add != 0.0));
     if (interior) {
-      double* dst = a.K + (long)(r0 + wid * 16) * a.ldk + c;
-#pragma unroll 2
+      double* dst = a.K + (long)(r0 + wid * 16) * a.ldk + c0 + 2 * lane;
       for (int rr = 0; rr < 16; ++rr) {
         const double* xr = xs + (wid * 16 + rr) * d;
-        double s0 = 0.0, s1 = 0.0;
+        double s[CP][2];
 #pragma unroll
-        for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
+        for (int q = 0; q < CP; ++q) s[q][0] = s[q][1] = 0.0;
+#pragma unroll
+        for (int k = 0; k < DD; ++k) {
           if (k < d) {
             const double x = xr[k];
-            const double d0 = x - z0[k], d1 = x - z1[k];
-            s0 = fma(d0, d0, s0);
-            s1 = fma(d1, d1, s1);
+#pragma unroll
+            for (int q = 0; q < CP; ++q) {
+              const double d0 = x - z[q][0][k], d1 = x - z[q][1][k];
+              s[q][0] = fma(d0, d0, s[q][0]);
+              s[q][1] = fma(d1, d1, s[q][1]);
+            }
           }
         }
-        const double k0 = a.sigma * exp_nonpos(-0.5 * s0);
-        const double k1 = a.sigma * exp_nonpos(-0.5 * s1);
-        *reinterpret_cast<v2d*>(dst) = (v2d){k0, k1};
+#pragma unroll
+        for (int q = 0; q < CP; ++q)
+          *reinterpret_cast<v2d*>(dst + q * GT_COLS) = (v2d){exp_neg_tab(s[q][0], stab), exp_neg_tab(s[q][1], stab)};
         dst += a.ldk;
       }
       continue;
@@ -131,29 +168,34 @@ __global__ __launch_bounds__(GT_THREADS) void gram_kernel(const GramArgs a) {
       const int r = wid * 16 + rr;
       const int gr = r0 + r;
       if (gr >= a.n1) break;
-      double s0 = 0.0, s1 = 0.0;
+      for (int q = 0; q < CP; ++q) {
+        const int c = c0 + q * GT_COLS + 2 * lane;
+        if (c >= a.n2) break;
+        if (a.lower && c0 + q * GT_COLS > r0 + GT_ROWS - 1) break;   // this 128-column piece lies above the diagonal
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < (D > 0 ? D : GPX_MAXD); ++k) {
-        if (k < d) {
-          const double x = xs[r * d + k];
-          const double d0 = x - z0[k], d1 = x - z1[k];
-          s0 = fma(d0, d0, s0);
-          s1 = fma(d1, d1, s1);
+        for (int k = 0; k < DD; ++k) {
+          if (k < d) {
+            const double x = xs[r * d + k];
+            const double d0 = x - z[q][0][k], d1 = x - z[q][1][k];
+            s0 = fma(d0, d0, s0);
+            s1 = fma(d1, d1, s1);
+          }
         }
-      }
-      double k0 = a.sigma * exp_nonpos(-0.5 * s0);
-      double k1 = a.sigma * exp_nonpos(-0.5 * s1);
-      if (gr == c) k0 += a.diag_add;
-      if (gr == c + 1) k1 += a.diag_add;
-      if (a.lower) {
-        if (c > gr) k0 = 0.0;
-        if (c + 1 > gr) k1 = 0.0;
-      }
-      double* dst = a.K + (long)gr * a.ldk + c;
-      if (c + 1 < a.n2) {
-        *reinterpret_cast<v2d*>(dst) = (v2d){k0, k1};
-      } else if (c < a.n2) {
-        dst[0] = k0;
+        double k0 = exp_neg_tab(s0, stab);
+        double k1 = exp_neg_tab(s1, stab);
+        if (gr == c) k0 += a.diag_add;
+        if (gr == c + 1) k1 += a.diag_add;
+        if (a.lower) {
+          if (c > gr) k0 = 0.0;
+          if (c + 1 > gr) k1 = 0.0;
+        }
+        double* dst = a.K + (long)gr * a.ldk + c;
+        if (c + 1 < a.n2) {
+          *reinterpret_cast<v2d*>(dst) = (v2d){k0, k1};
+        } else {
+          dst[0] = k0;
+        }
       }
     }
   }
@@ -407,10 +449,21 @@ int gpx_gram_launch(hipStream_t s, const double* X1, int n1, long ldx1, const do
   a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1;
   a.X2 = X2; a.ldx2 = ldx2; a.n2 = n2;
   a.d = d; a.sigma = sigma; a.diag_add = diag_add; a.K = K; a.ldk = ldk; a.lower = uplo == GPX_LOWER;
-  for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(hb.b[k]) : 0.0;
-  dim3 grid((n2 + GT_COLS - 1) / GT_COLS, (n1 + GT_SUBS * GT_ROWS - 1) / (GT_SUBS * GT_ROWS));
+  for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(0.5 * hb.b[k]) : 0.0;
+  for (int j = 0; j < EXP_TAB; ++j) a.tab[j] = (double)((long double)sigma * exp2l((long double)j / EXP_TAB));
   dispatch_d(d, [&](auto D) {
-    hipLaunchKernelGGL((gram_kernel<decltype(D)::value>), grid, dim3(GT_THREADS), 0, s, a);
+    constexpr int DV = decltype(D)::value;
+    // 512-column strips for full matrices where the per-lane columns fit in registers (compiled d) and the
+    // matrix is wide enough to fill them (n = 65536, d = 8: 6.78 against 6.90 ms); 128-column strips
+    // otherwise: runtime d <= 32, narrow matrices such as k*, and lower-triangle launches, whose tiles on
+    // the diagonal take the predicated path and are 4x larger with wide strips (no gain measured)
+    if (DV > 0 && n2 >= 4 * GT_COLS && !a.lower) {
+      dim3 grid((n2 + 4 * GT_COLS - 1) / (4 * GT_COLS), (n1 + GT_SUBS * GT_ROWS - 1) / (GT_SUBS * GT_ROWS));
+      hipLaunchKernelGGL((gram_kernel<DV, (DV > 0 ? 4 : 1)>), grid, dim3(GT_THREADS), 0, s, a);
+    } else {
+      dim3 grid((n2 + GT_COLS - 1) / GT_COLS, (n1 + GT_SUBS * GT_ROWS - 1) / (GT_SUBS * GT_ROWS));
+      hipLaunchKernelGGL((gram_kernel<DV, 1>), grid, dim3(GT_THREADS), 0, s, a);
+    }
   });
   GPX_HIP(hipGetLastError());
   return 0;
