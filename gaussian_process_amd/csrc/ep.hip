@@ -49,102 +49,185 @@ __device__ inline double reduce8(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(THREADS) void ep_site_kernel(int n, int i, int t, const double* Sigma, long ld,
-                                                          double* Sbuf, double* Tbuf, double* coef,
-                                                          const double* y, SiteState in, SiteState out) {
-  __shared__ double w[EPB];        // coef_j * s_j[i], zero for j >= t
-  __shared__ double wred[THREADS / 64];
-  __shared__ double sc[4];         // coef_t, gamma, tau_new, nu_new
+// MS consecutive sites per launch.  Every workgroup repeats, identically, the whole scalar recursion of
+// the group: nothing it needs of the columns formed INSIDE the launch lies outside its reach.  With
+// rows(q) = Sbuf[i_q, :t0] (the site rows of the columns already there), w_p = coef o rows(p),
+//   G[q][p] = rows(q) . w_p                                   (MS x MS dots of length t0)
+//   E[q][p] = s_p[i_q] = Sigma_0[i_q, i_p] + G[q][p] + sum_{p' < p} E[q][p'] coef_p' E[p][p']
+// give, site after site, Sigma_ii = E[p][p] and mu_i = mu_in[i_p] + sum_{p' < p} gamma_p' E[p][p'],
+// hence the moment match and coef_p, gamma_p; then each workgroup forms its 32 rows of all MS columns,
+//   s_p[r] = Sigma_0[r, i_p] + Sbuf[r, :t0] . w_p + sum_{p' < p} s_p'[r] coef_p' E[p][p'],
+// reading its rows of Sbuf ONCE for the MS columns.  One launch, one pass over Sbuf and one round of
+// memory latency serve MS sites; what stays serial per site is the scalar moment match (~1 us).
+// (One site per launch: 6.3 us per site, of which ~4 us were launch gap and dependent load latency.)
+constexpr int MS = 8;               // sites per launch = threads per row (lane `sub` fetches site sub's base entry)
+
+struct SiteGroup {
+  int m;            // sites in this launch, 1 <= m <= MS, pairwise distinct
+  int t0;           // columns of Sbuf / Tbuf already filled in this delayed block; the group fills [t0, t0 + m)
+  int idx[MS];      // their site indices
+};
+
+__device__ __forceinline__ double sym_lower(const double* Sigma, long ld, int r, int c) {
+  return r >= c ? Sigma[(long)r * ld + c] : Sigma[(long)c * ld + r];
+}
+
+__global__ __launch_bounds__(THREADS) void ep_sites_kernel(int n, SiteGroup grp, const double* Sigma, long ld,
+                                                           double* Sbuf, double* Tbuf, double* coef,
+                                                           const double* y, SiteState in, SiteState out) {
+  __shared__ double rowS[MS][EPB];   // Sbuf[i_q, j], zero for j >= t0
+  __shared__ double wv[MS][EPB];     // coef_j * Sbuf[i_p, j]
+  __shared__ double S0[MS][MS];      // Sigma_0[i_q, i_p]
+  __shared__ double Gm[MS][MS];
+  __shared__ double Em[MS][MS];      // E[q][p] (LDS, not a private array: dynamic indexing would go to scratch)
+  __shared__ double cE[MS][MS];      // coef_p' * E[p][p'], p' < p
+  __shared__ double stv[MS][4];      // mu, tau, nu, y at the sites
+  __shared__ double scv[MS][4];      // coef_p, gamma_p, tau_new, nu_new
   const int tid = threadIdx.x;
-  const int tpad = (t + 15) & ~15;
+  const int m = grp.m, t0 = grp.t0;
+  const int tpad = (t0 + 15) & ~15;
 
-  // ---- loads that do not depend on anything computed here go first, so their latency overlaps ----
-  const int r = blockIdx.x * ROWS + (tid >> 3);
-  const int sub = tid & 7;
-  double sig_ii = 0.0, mu_i = 0.0, yi = 0.0, tau_i = 0.0, nu_i = 0.0;
-  if (tid == 0) {
-    sig_ii = Sigma[(long)i * ld + i];
-    mu_i = in.mu[i];
-    yi = y[i];
-    tau_i = in.tau[i];
-    nu_i = in.nu[i];
-  }
+  // ---- phase 1: everything that depends only on the state before the launch ----
+  const int rl = tid >> 3, sub = tid & 7;
+  const int r = blockIdx.x * ROWS + rl;
   double base = 0.0, mu_r = 0.0, tau_r = 0.0, nu_r = 0.0;
-  if (r < n && sub == 0) {
-    base = r <= i ? Sigma[(long)i * ld + r] : Sigma[(long)r * ld + i];   // column i of the symmetric Sigma_0
-    mu_r = in.mu[r];
-    tau_r = in.tau[r];
-    nu_r = in.nu[r];
-  }
-
-  // ---- scalars of site i (repeated identically in every workgroup) ----
-  double part = 0.0;
-  if (tid < EPB) {
-    double wj = 0.0;
-    if (tid < t) {
-      const double sij = Sbuf[(long)i * EPB + tid];
-      wj = coef[tid] * sij;
-      part = wj * sij;
+  if (r < n) {
+    if (sub < m) base = sym_lower(Sigma, ld, r, grp.idx[sub]);   // lane `sub`: column i_sub of Sigma_0 at row r
+    if (sub == 0) {
+      mu_r = in.mu[r];
+      tau_r = in.tau[r];
+      nu_r = in.nu[r];
     }
-    w[tid] = wj;
   }
-  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-  if ((tid & 63) == 0) wred[tid >> 6] = part;
+  for (int e = tid; e < MS * EPB; e += THREADS) {   // rows of the unused slots (q >= m) are zero
+    const int q = e / EPB, j = e - q * EPB;
+    double v = 0.0, c = 0.0;
+    if (q < m && j < t0) {
+      v = Sbuf[(long)grp.idx[q] * EPB + j];
+      c = coef[j];
+    }
+    rowS[q][j] = v;
+    wv[q][j] = c * v;
+  }
+  if (tid < m * MS) {
+    const int q = tid / MS, p2 = tid % MS;
+    if (p2 < m) S0[q][p2] = sym_lower(Sigma, ld, grp.idx[q], grp.idx[p2]);
+  }
+  if (tid < m) {
+    const int i = grp.idx[tid];
+    stv[tid][0] = in.mu[i];
+    stv[tid][1] = in.tau[i];
+    stv[tid][2] = in.nu[i];
+    stv[tid][3] = y[i];
+  }
   __syncthreads();
-  if (tid == 0) {
-    double corr = 0.0;
-    for (int q = 0; q < THREADS / 64; ++q) corr += wred[q];
-    const double sii = sig_ii + corr;
-    const double tau_cav = 1.0 / sii - tau_i;
-    const double nu_cav = mu_i / sii - nu_i;
-    const double dom = tau_cav * tau_cav + tau_cav;
-    const double rdom = sqrt(dom);
-    const double z = yi * nu_cav / rdom;
-    const double ratio = 0.7978845608028654 / erfcx(-z * 0.7071067811865476);   // phi(z) / Phi(z)
-    const double mu_hat = nu_cav / tau_cav + yi * ratio / rdom;
-    const double var_hat = 1.0 / tau_cav - ratio / dom * (z + ratio);
-    const double dtau = 1.0 / var_hat - tau_cav - tau_i;
-    const double nu_new = mu_hat / var_hat - nu_cav;
-    const double dnu = nu_new - nu_i;
-    const double cf = -dtau / (1.0 + dtau * sii);
-    sc[0] = cf;
-    sc[1] = dnu + cf * (mu_i + sii * dnu);
-    sc[2] = tau_i + dtau;
-    sc[3] = nu_new;
-    if (blockIdx.x == 0) coef[t] = cf;
+  {   // G[q][p]: 4 threads per pair, 64 pairs
+    const int pair = tid >> 2, part = tid & 3;
+    const int q = pair / MS, p2 = pair % MS;
+    double acc = 0.0;
+    if (q < m && p2 < m)
+      for (int j = part; j < tpad; j += 4) acc = fma(rowS[q][j], wv[p2][j], acc);
+    acc += __shfl_xor(acc, 1, 4);
+    acc += __shfl_xor(acc, 2, 4);
+    if (part == 0) Gm[q][p2] = acc;
   }
+  __syncthreads();
 
-  // ---- rows of the column s_t (needs only w, available since the barrier above) ----
-  double acc = 0.0;
+  // ---- phase 2: the sites one after the other (scalars; repeated identically in every workgroup) ----
+  // Lanes 0 .. MS-1 of wave 0 all run the moment match of site p (same inputs, same result); lane q > p
+  // then forms its own entry E[q][p] of the new column, so the m - p - 1 entries cost one step, not m.
+  // Reciprocals are shared (1 / Sigma_ii, 1 / sqrt(dom), 1 / tau_cav, 1 / var_hat): 6 divisions per site
+  // instead of 11 on the serial path; the results differ from the division-by-division form by rounding.
+  if (tid < MS) {
+    const int q = tid;
+#pragma unroll 1
+    for (int p2 = 0; p2 < m; ++p2) {
+      double sii = S0[p2][p2] + Gm[p2][p2];
+      double mu_i = stv[p2][0];
+      for (int pp = 0; pp < p2; ++pp) {
+        sii = fma(cE[p2][pp], Em[p2][pp], sii);
+        mu_i = fma(scv[pp][1], Em[p2][pp], mu_i);
+      }
+      const double tau_i = stv[p2][1], nu_i = stv[p2][2], yi = stv[p2][3];
+      const double inv_sii = 1.0 / sii;
+      const double tau_cav = inv_sii - tau_i;
+      const double nu_cav = mu_i * inv_sii - nu_i;
+      const double dom = tau_cav * tau_cav + tau_cav;
+      const double inv_rdom = 1.0 / sqrt(dom);
+      const double z = yi * nu_cav * inv_rdom;
+      const double ratio = 0.7978845608028654 / erfcx(-z * 0.7071067811865476);   // phi(z) / Phi(z)
+      const double inv_tc = 1.0 / tau_cav;
+      const double mu_hat = nu_cav * inv_tc + yi * ratio * inv_rdom;
+      const double var_hat = inv_tc - ratio * (inv_rdom * inv_rdom) * (z + ratio);
+      const double inv_var = 1.0 / var_hat;
+      const double dtau = inv_var - tau_cav - tau_i;
+      const double nu_new = mu_hat * inv_var - nu_cav;
+      const double dnu = nu_new - nu_i;
+      const double c = -dtau / (1.0 + dtau * sii);
+      // entry of the new column at the row of the later site q (lane q), and its scaled copy
+      double e = 0.0;
+      if (q > p2 && q < m) {
+        e = S0[q][p2] + Gm[q][p2];
+        for (int pp = 0; pp < p2; ++pp) e = fma(Em[q][pp], cE[p2][pp], e);
+      }
+      if (q == 0) {
+        scv[p2][0] = c;
+        scv[p2][1] = dnu + c * (mu_i + sii * dnu);
+        scv[p2][2] = tau_i + dtau;
+        scv[p2][3] = nu_new;
+        if (blockIdx.x == 0) coef[t0 + p2] = c;
+      }
+      if (q > p2 && q < m) {
+        Em[q][p2] = e;
+        cE[q][p2] = c * e;
+      }
+      // (one wave: its LDS writes are visible to its own later reads in program order)
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: this workgroup's rows of the m new columns ----
+  double dsum[MS];
+#pragma unroll
+  for (int p2 = 0; p2 < MS; ++p2) dsum[p2] = 0.0;
   if (r < n) {
     const double* srow = Sbuf + (long)r * EPB;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int j = 2 * sub;
-    for (; j + 48 < tpad; j += 64) {   // four independent 16-byte loads in flight
-      const v2d s0 = *reinterpret_cast<const v2d*>(srow + j);
-      const v2d s1 = *reinterpret_cast<const v2d*>(srow + j + 16);
-      const v2d s2 = *reinterpret_cast<const v2d*>(srow + j + 32);
-      const v2d s3 = *reinterpret_cast<const v2d*>(srow + j + 48);
-      a0 = fma(s0.y, w[j + 1], fma(s0.x, w[j], a0));
-      a1 = fma(s1.y, w[j + 17], fma(s1.x, w[j + 16], a1));
-      a2 = fma(s2.y, w[j + 33], fma(s2.x, w[j + 32], a2));
-      a3 = fma(s3.y, w[j + 49], fma(s3.x, w[j + 48], a3));
-    }
-    for (; j < tpad; j += 16) {
+    for (int j = 2 * sub; j < tpad; j += 16) {
       const v2d sv = *reinterpret_cast<const v2d*>(srow + j);
-      a0 = fma(sv.y, w[j + 1], fma(sv.x, w[j], a0));
+#pragma unroll
+      for (int p2 = 0; p2 < MS; ++p2) dsum[p2] = fma(sv.y, wv[p2][j + 1], fma(sv.x, wv[p2][j], dsum[p2]));
     }
-    acc = (a0 + a1) + (a2 + a3);
   }
-  acc = reduce8(acc);
-  __syncthreads();   // sc[] from thread 0
+#pragma unroll
+  for (int p2 = 0; p2 < MS; ++p2) {
+    dsum[p2] = reduce8(dsum[p2]);
+    // lane 0 of the row collects site p2's base entry from lane p2
+    const double b = __shfl(base, (tid & 56) + p2, 64);
+    dsum[p2] += b;
+  }
   if (r < n && sub == 0) {
-    const double col = base + acc;
-    Sbuf[(long)r * EPB + t] = col;
-    Tbuf[(long)r * EPB + t] = sc[0] * col;
-    out.mu[r] = fma(sc[1], col, mu_r);
-    out.tau[r] = r == i ? sc[2] : tau_r;
-    out.nu[r] = r == i ? sc[3] : nu_r;
+    double sc[MS];
+    double mu_new = mu_r, tau_new = tau_r, nu_new = nu_r;
+#pragma unroll
+    for (int p2 = 0; p2 < MS; ++p2) {
+      if (p2 < m) {
+        double col = dsum[p2];
+#pragma unroll
+        for (int pp = 0; pp < MS; ++pp)
+          if (pp < p2) col = fma(sc[pp], cE[p2][pp], col);
+        sc[p2] = col;
+        Sbuf[(long)r * EPB + t0 + p2] = col;
+        Tbuf[(long)r * EPB + t0 + p2] = scv[p2][0] * col;
+        mu_new = fma(scv[p2][1], col, mu_new);
+        if (r == grp.idx[p2]) {
+          tau_new = scv[p2][2];
+          nu_new = scv[p2][3];
+        }
+      }
+    }
+    out.mu[r] = mu_new;
+    out.tau[r] = tau_new;
+    out.nu[r] = nu_new;
   }
 }
 
@@ -220,18 +303,34 @@ int gpx_ep_sweep_launch(hipStream_t s, int n, double* Sigma, long ld, const doub
   g.M = n; g.N = n; g.K = EPB; g.alpha = 1.0; g.beta = 1.0;
   g.c_lower = 1; g.diag_add = 0.0; g.inplace = GPX_INPLACE_NONE;
 
-  for (int k = 0; k < count; ++k) {
+  int launches = 0;
+  for (int k = 0; k < count;) {
     const int t = k % EPB;
     if (t == 0) GPX_HIP(hipMemsetAsync(Sbuf, 0, 2 * (size_t)n * EPB * sizeof(double), s));   // Sbuf and Tbuf
-    hipLaunchKernelGGL(ep_site_kernel, dim3(grid), dim3(THREADS), 0, s, n, order_host[k], t, Sigma, ld, Sbuf, Tbuf,
-                       coef, y, st[k & 1], st[(k + 1) & 1]);
-    if (t == EPB - 1 || k == count - 1) {
-      g.K = (t + 16) & ~15;   // columns beyond t are zero
+    // the next group: up to MS sites, inside this delayed block, pairwise distinct
+    SiteGroup grp;
+    grp.t0 = t;
+    grp.m = 0;
+    while (grp.m < MS && k + grp.m < count && t + grp.m < EPB) {
+      const int i = order_host[k + grp.m];
+      bool dup = false;
+      for (int q = 0; q < grp.m; ++q) dup = dup || grp.idx[q] == i;
+      if (dup) break;
+      grp.idx[grp.m++] = i;
+    }
+    for (int q = grp.m; q < MS; ++q) grp.idx[q] = grp.idx[0];
+    hipLaunchKernelGGL(ep_sites_kernel, dim3(grid), dim3(THREADS), 0, s, n, grp, Sigma, ld, Sbuf, Tbuf, coef, y,
+                       st[launches & 1], st[(launches + 1) & 1]);
+    ++launches;
+    k += grp.m;
+    if (k % EPB == 0 || k == count) {
+      const int tl = (k - 1) % EPB;     // last column filled
+      g.K = (tl + 16) & ~15;            // columns beyond it are zero
       const int rc = gpx_gemm_launch(s, g);
       if (rc != 0) return rc;
     }
   }
-  const SiteState& fin = st[count & 1];
+  const SiteState& fin = st[launches & 1];
   hipLaunchKernelGGL(ep_copy2_kernel, dim3(g1), dim3(256), 0, s, n, fin.tau, fin.nu, tau, nu);
   GPX_HIP(hipGetLastError());
   return 0;
