@@ -105,7 +105,20 @@ __global__ __launch_bounds__(GT_THREADS) void gram_kernel(const GramArgs a) {
   __shared__ double sx1[GT_SUBS * GT_ROWS * DD];
   __shared__ double stab[EXP_TAB];
   const int d = D > 0 ? D : a.d;
-  const int rb = blockIdx.y * (GT_SUBS * GT_ROWS), c0 = blockIdx.x * COLS;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.lower && CP == 1) {
+    // lower triangle: a 1-D grid over the live (row block, strip) pairs only -- row block b has the strips
+    // 0 .. 2 b + 1 (a 2-D grid launches as many workgroups again that exit at once: 65 536 of them at
+    // n = 65536).  id = b (b + 1) + strip.
+    const unsigned id = blockIdx.x;
+    unsigned b = (unsigned)((sqrt(4.0 * (double)id + 1.0) - 1.0) * 0.5);
+    while ((b + 1) * (b + 2) <= id) ++b;
+    while (b * (b + 1) > id) --b;
+    by = (int)b;
+    bx = (int)(id - b * (b + 1));
+  }
+  const int rb = by * (GT_SUBS * GT_ROWS), c0 = bx * COLS;
+  if (c0 >= a.n2) return;                                  // (ragged last row block of the packed grid)
   if (a.lower && c0 > rb + GT_SUBS * GT_ROWS - 1) return;  // every sub-tile strictly above the diagonal
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   if (t < EXP_TAB) stab[t] = a.tab[t];
@@ -462,6 +475,7 @@ int gpx_gram_launch(hipStream_t s, const double* X1, int n1, long ldx1, const do
       hipLaunchKernelGGL((gram_kernel<DV, (DV > 0 ? 4 : 1)>), grid, dim3(GT_THREADS), 0, s, a);
     } else {
       dim3 grid((n2 + GT_COLS - 1) / GT_COLS, (n1 + GT_SUBS * GT_ROWS - 1) / (GT_SUBS * GT_ROWS));
+      if (a.lower) grid = dim3(grid.y * (grid.y + 1), 1);   // packed: live (row block, strip) pairs, see the kernel
       hipLaunchKernelGGL((gram_kernel<DV, 1>), grid, dim3(GT_THREADS), 0, s, a);
     }
   });
