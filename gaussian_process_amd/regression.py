@@ -121,6 +121,21 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         the device in batches."""
         return self.predict_with_variance(X, full_cov=False)[0]
 
+    def _predict_buffers(self, m, full_cov, need_Ks):
+        """Prediction workspaces (V and, after a gradient pass, k*: n x m each; the m x m covariance), kept
+        with the estimator and reused by later calls with the same number of test points -- a streamed
+        prediction or an optimiser loop does not allocate per call (2 x 2.1 GB at n = 65536, m = 4096)."""
+        dv = self._dev
+        rt = dv["rt"]
+        pb = dv.get("pred")
+        if pb is None or pb["m"] != m:
+            pb = dv["pred"] = dict(m=m, V=rt.matrix(self.n, m), Ks=None, mean=rt.vector(m), cov=None, var=rt.vector(m))
+        if need_Ks and pb["Ks"] is None:
+            pb["Ks"] = rt.matrix(self.n, m)
+        if full_cov and pb["cov"] is None:
+            pb["cov"] = rt.matrix(m, m)
+        return pb["V"], pb["Ks"], pb["mean"], pb["cov"] if full_cov else None, None if full_cov else pb["var"]
+
     @on_device
     def predict_with_variance(self, X, full_cov=True, batch=16384):
         """(mean (m,), cov (m, m)) as regression.py:31-44; ``full_cov=False`` returns the
@@ -142,10 +157,7 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         key = st["key"]
         _, beta_p = _keep = _lib.host_doubles(np.array(key[2]))
         dXs = rt.upload_matrix(X)
-        V = rt.matrix(self.n, m)
-        mean = rt.vector(m)
-        cov = rt.matrix(m, m) if full_cov else None
-        var = None if full_cov else rt.vector(m)
+        V, Ks, mean, cov, var = self._predict_buffers(m, full_cov, need_Ks=not st["has_factor"])
         if st["has_factor"]:
             rc = rt.lib.gpx_gpr_predict(
                 rt.h, key[0], ptr(dv["X"]), self.n, dv["X"].shape[1], self.dim, key[1], beta_p, key[3],
@@ -155,7 +167,6 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
             _lib.check(rc, "gpx_gpr_predict")
         else:
             # the gradient pass left W = L^-1 in Ky and a = L^-1 y in dv["a"]: V = W k*, no refactorisation
-            Ks = rt.matrix(self.n, m)
             rc = rt.lib.gpx_gpr_predict_inv(
                 rt.h, key[0], ptr(dv["X"]), self.n, dv["X"].shape[1], self.dim, key[1], beta_p, key[3],
                 ptr(dv["a"]), ptr(dv["Ky"]), dv["Ky"].shape[1], ptr(dXs), m, dXs.shape[1], ptr(Ks),

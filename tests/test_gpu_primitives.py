@@ -87,6 +87,23 @@ def test_gemm_multi_round_launches(rt, ta, tb, M, N, K):
     assert np.max(np.abs(got - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))   # no tile skipped or done twice
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (1, 0)])
+def test_gemm_very_long_k_runs_in_chunks(rt, ta, tb):
+    """K >= 16384 with plain operands is issued as consecutive launches of K = 8192 (the last one takes
+    the remainder, here 8192 + 70): same product, C read once with beta and re-read with 1 afterwards,
+    for k-contiguous and row-contiguous operands.  The host product is the checker (NumPy, fp64)."""
+    M, N, K = 4096, 4096, 3 * 8192 + 70
+    rng = np.random.default_rng(K + ta)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    Cm = rng.standard_normal((M, N))
+    dA, dB, dC = up(rt, A), up(rt, B), up(rt, Cm)
+    ok(rt.lib.gpx_gemm(rt.h, ta, tb, M, N, K, -0.5, P(dA), dA.shape[1], P(dB), dB.shape[1], 0.25,
+                       P(dC), dC.shape[1]))
+    ref = 0.25 * Cm - 0.5 * ((A.T if ta else A) @ (B.T if tb else B))
+    assert relerr(down(rt, dC, M, N), ref) < 1e-13
+
+
 # ----------------------------------------------------------------------------- Gram
 @pytest.mark.parametrize("kind,d", [("rbf", 1), ("rbf", 3), ("ard", 2), ("ard", 8), ("ard", 5)])
 @pytest.mark.parametrize("n1,n2", [(1, 1), (15, 50), (129, 257), (300, 300)])
