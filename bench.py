@@ -168,8 +168,18 @@ def cpu_baseline(n_cpu, m_cpu):
     8x slower (0.034 against 0.27 TFLOP/s).  The child never touches the GPU."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-only", "--cpu-n", str(n_cpu), "--cpu-m", str(m_cpu)]
+    # all the host cores this process may use, whatever the launcher set (torch.distributed.run exports
+    # OMP_NUM_THREADS=1 to the ranks of a multi-process job: the baseline would run on one core)
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900, check=True)
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))     # the GPU boxes give one GPU's job 16 host cores
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env[k] = str(cores)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=420, check=True, env=env)
         return json.loads(r.stdout.decode().strip().splitlines()[-1])
     except Exception as e:   # the GPU line must not be lost to a host-side failure
         return {"value": None, "unit": "TFLOP/s", "cores": 0, "kind": "port", "sample": "cpu baseline failed: %r" % (e,)}

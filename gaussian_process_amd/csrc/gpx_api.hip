@@ -532,10 +532,11 @@ int gpx_diag(gpx_handle* h, int n, const double* A, int lda, double* diag_out) {
 }
 
 static int finish_grad(int nbeta, double sigma, const BetaArg& b, const double* raw, double* out) {
-  // raw[0] = tr(A); raw[1] = sum A o K / sigma; raw[2+k] = sum A o (K/sigma) * beta_k diff_k
+  // raw[0] = tr(A); raw[1] = sum A o K / sigma; raw[2+k] = sum A o (K/sigma) * beta_k diff_k / 2 (the kernel
+  // works with coordinates scaled by sqrt(beta_k / 2))
   out[0] = 0.5 * raw[0];
   out[1] = 0.5 * raw[1];
-  for (int k = 0; k < nbeta; ++k) out[2 + k] = -0.25 * sigma * raw[2 + k] / b.b[k];
+  for (int k = 0; k < nbeta; ++k) out[2 + k] = -0.5 * sigma * raw[2 + k] / b.b[k];
   return 0;
 }
 

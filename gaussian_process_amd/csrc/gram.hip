@@ -22,14 +22,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int GT_ROWS = 64, GT_COLS = 128, GT_THREADS = 256, GT_SUBS = 4;
 
-// exp(x) for x <= 0 (the only argument range a stationary kernel produces): Cody-Waite reduction
-// x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial in Horner form (truncation 4e-18
-// relative), scaling by v_ldexp_f64 (gradual underflow to 0 below x = -745).  19 fp64 VALU
-// instructions against ~45 for the general-range library routine: the Gram kernel is priced
-// against HBM, and at d = 8 the library exp alone kept it VALU-bound.  Max error < 1 ulp + the
-// rounding of the final ldexp (exact unless denormal).
 // Horner step with the coefficient in an SGPR pair: p*r + c as ONE v_fma_f64.  (Left to itself the
-// compiler keeps the 11 non-inline coefficients in VGPRs and pairs every v_fmac with a v_mov_b64,
+// compiler keeps the non-inline coefficients in VGPRs and pairs every v_fmac with a v_mov_b64,
 // which doubles the instruction count of the polynomial.)
 __device__ __forceinline__ double horner(double p, double r, double c) {
   double o;
@@ -37,34 +31,14 @@ __device__ __forceinline__ double horner(double p, double r, double c) {
   return o;
 }
 
-__device__ __forceinline__ double exp_nonpos(double x) {
-  x = x < -800.0 ? -800.0 : x;   // (NaN stays NaN)
-  const double kf = rint(x * 1.44269504088896338700e+00);
-  double r = fma(kf, -6.93147180369123816490e-01, x);
-  r = fma(kf, -1.90821492927058770002e-10, r);
-  double p = horner(1.6059043836821613e-10, r, 2.08767569878681e-09);   // 1/13!, 1/12!
-  p = horner(p, r, 2.505210838544172e-08);         // 1/11!
-  p = horner(p, r, 2.755731922398589e-07);         // 1/10!
-  p = horner(p, r, 2.7557319223985893e-06);        // 1/9!
-  p = horner(p, r, 2.48015873015873e-05);          // 1/8!
-  p = horner(p, r, 1.984126984126984e-04);         // 1/7!
-  p = horner(p, r, 1.388888888888889e-03);         // 1/6!
-  p = horner(p, r, 8.333333333333333e-03);         // 1/5!
-  p = horner(p, r, 4.1666666666666664e-02);        // 1/4!
-  p = horner(p, r, 1.6666666666666666e-01);        // 1/3!
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)kf);
-}
-
-// exp for the Gram kernel proper: K = sigma * exp(-h), h = 0.5 * sum_k beta_k (x_k - x'_k)^2 >= 0 handed
+// exp for the Gram and trace kernels: K = sigma * exp(-h), h = 0.5 * sum_k beta_k (x_k - x'_k)^2 >= 0 handed
 // over already halved (the coordinates are pre-scaled by sqrt(beta_k / 2)).  Table-driven: with
 // kf = rint(-h * 64 / ln 2) = 64 e + j,  exp(-h) = 2^e * 2^(j/64) * exp(r),  |r| <= ln 2 / 128, so a
 // degree-5 Taylor polynomial suffices (truncation r^6 / 720 < 4e-17) and sigma * 2^(j/64) comes from a
-// 64-entry table in LDS (one ds_read per element).  15 VALU instructions per element against 24 for
-// exp_nonpos + scaling: at d = 8 the kernel was bound by its fp64 VALU work (40 instructions per
-// element), not by the stores.  Error < 1.5 ulp; underflows gradually through v_ldexp_f64.
+// 64-entry table in LDS (one ds_read per element).  15 VALU instructions per element against 24 for the
+// round-1 routine (Cody-Waite + degree-13 Horner, then the scaling by sigma): at d = 8 the Gram kernel was
+// bound by its fp64 VALU work (40 instructions per element), not by the stores.  Error < 1.5 ulp;
+// underflows gradually through v_ldexp_f64.  The coefficients sit in SGPR pairs (see horner()).
 constexpr int EXP_TAB = 64;
 
 __device__ __forceinline__ double exp_neg_tab(double h, const double* tab) {
@@ -264,7 +238,8 @@ struct TraceArgs {
   // the same; only the tile tests are mirrored.
   int upper; const double* kdiag;
   double* partials;  // [nblocks][nacc]
-  BetaArg sb;        // sqrt(beta_k)
+  BetaArg sb;        // sqrt(beta_k / 2): the squared differences below are beta_k diff_k^2 / 2 (the host doubles the sums)
+  double tab[EXP_TAB];  // 2^(j/64): K_ij / sigma = exp_neg_tab(sum_k beta_k diff_k^2 / 2)
 };
 
 constexpr int TR_MAXACC = GPX_MAXD + 2;
@@ -285,6 +260,7 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
   __shared__ double sx1[SUBS * GT_ROWS * DD];
   __shared__ double sal[SUBS * GT_ROWS];
   __shared__ double sred[4][TR_MAXACC];
+  __shared__ double stab[EXP_TAB];
   const int d = D > 0 ? D : a.d;
   const int nacc = 2 + a.nbeta;
   const int rb = band_row0 + blockIdx.y * (SUBS * GT_ROWS), c0 = blockIdx.x * GT_COLS;
@@ -300,6 +276,7 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
   for (int q = 0; q < 2 + DD; ++q) acc[q] = 0.0;
 
   if (!skip) {
+    if (t < EXP_TAB) stab[t] = a.tab[t];
     for (int e = t; e < rows_here * d; e += GT_THREADS) {
       const int r = e / d, k = e - r * d;
       sx1[e] = a.X[(long)(a.roff + rb + r) * a.ldx + k] * a.sb.b[k];
@@ -348,8 +325,8 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
               s1 += e1[k];
             }
           }
-          const double w0 = 2.0 * (ai * al0 - q[0]) * exp_nonpos(-0.5 * s0);
-          const double w1 = 2.0 * (ai * al1 - q[1]) * exp_nonpos(-0.5 * s1);
+          const double w0 = 2.0 * (ai * al0 - q[0]) * exp_neg_tab(s0, stab);
+          const double w1 = 2.0 * (ai * al1 - q[1]) * exp_neg_tab(s1, stab);
           acc[1] += w0 + w1;
           if (a.nbeta == 1) {
             acc[2] += w0 * s0 + w1 * s1;
@@ -395,8 +372,8 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
         }
         const double A0 = v0 ? ai * al0 - q0 : 0.0;
         const double A1 = v1 ? ai * al1 - q1 : 0.0;
-        const double w0 = v0 ? (gc == gr ? 1.0 : 2.0) * A0 * exp_nonpos(-0.5 * s0) : 0.0;
-        const double w1 = v1 ? (gc + 1 == gr ? 1.0 : 2.0) * A1 * exp_nonpos(-0.5 * s1) : 0.0;
+        const double w0 = v0 ? (gc == gr ? 1.0 : 2.0) * A0 * exp_neg_tab(s0, stab) : 0.0;
+        const double w1 = v1 ? (gc + 1 == gr ? 1.0 : 2.0) * A1 * exp_neg_tab(s1, stab) : 0.0;
         if (v0 && gc == gr) acc[0] += A0;
         if (v1 && gc + 1 == gr) acc[0] += A1;
         acc[1] += w0 + w1;
@@ -505,7 +482,8 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int n
   a.upper = kdiag != nullptr; a.kdiag = kdiag;
   a.X = X; a.ldx = ldx; a.nr = nr; a.nc = nc; a.roff = roff; a.coff = coff; a.d = d; a.nbeta = nbeta;
   a.sigma = sigma; a.alpha = alpha; a.Kinv = Kinv; a.ldk = ldk; a.partials = red;
-  for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(hb.b[k]) : 0.0;
+  for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(0.5 * hb.b[k]) : 0.0;
+  for (int j = 0; j < EXP_TAB; ++j) a.tab[j] = (double)exp2l((long double)j / EXP_TAB);
   const int nacc = 2 + nbeta;
   int rc = 0;
   dispatch_d(d, [&](auto D) {
