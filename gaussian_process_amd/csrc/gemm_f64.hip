@@ -36,6 +36,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16, NTHREADS = 256;
+constexpr int SYNC_KT = 128;            // default k-tiles between two pacing points of a super-tile (a power of two)
+constexpr int SYNC_MAX_POLLS = 20000;   // x ~0.2 us: a workgroup gives up waiting after ~4 ms and goes on alone
 
 // LDS-DMA of 16 bytes per lane: global `src` (per lane) -> LDS `dst_wave` + lane * 16 (wave-uniform base).
 __device__ __forceinline__ void glds16(const char* src, double* dst_wave) {
@@ -221,6 +223,25 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
     bid = g.split_tile0 + bid / (unsigned)g.split_s;
   }
   if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bid, order, bi, bj)) return;
+  // Pacing (plain operands, super-tile mode, long K).  The 64 workgroups of a super-tile share 8 + 8 operand
+  // panels through their XCD's 4 MiB L2, which holds a window of only 16 k-tiles of those panels; nothing
+  // keeps the workgroups in step, and after the first round of a launch they start whenever a slot frees,
+  // so partners are rarely inside one window (measured: L2 hit rate 36 % on M = N = K = 16384, where lockstep
+  // would give 87 %).  Every SYNC_KT k-tiles thread 0 checks in at the super-tile's counter and waits --
+  // bounded, so a missing partner can only cost time -- until all live workgroups of the super-tile have
+  // reached the same k.  Workgroups are dispatched in id order, so all members of a super-tile are resident
+  // (or about to be) whenever one of them is.
+  unsigned* pace = nullptr;
+  unsigned pace_live = 0;
+  if (g.sync_cnt != nullptr && nsuper != 0) {
+    const unsigned xcd = bid & 7, idx = bid >> 3;
+    const unsigned st = (idx >> 6) * 8 + xcd;
+    int li, lj;
+    const bool alive = block_coords(tiles_m, tiles_n, g.c_lower, nsuper, (((idx >> 6) << 6) + (threadIdx.x & 63)) * 8 + xcd,
+                                    order, li, lj);
+    pace_live = (unsigned)__popcll(__ballot(alive));   // (every wave computes it; thread 0 uses it)
+    pace = g.sync_cnt + st;
+  }
   if (g.c_upper) {   // mirror image of the lower enumeration (symmetric product): tile (bj, bi) on or above the diagonal
     const int tmp = bi;
     bi = bj;
@@ -359,6 +380,16 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
               acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][x], fb[kk & 1][y], acc[x][y], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (pace != nullptr && cur == 0 && kt > kb && (((kt - kb) / BK) & (g.sync_kt - 1)) == 0) {
+          if (t == 0) {
+            const unsigned target = pace_live * (unsigned)((kt - kb) / (BK * g.sync_kt));
+            __hip_atomic_fetch_add(pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int polls = 0; polls < SYNC_MAX_POLLS; ++polls) {
+              if (__hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+              __builtin_amdgcn_s_sleep(8);
+            }
+          }
+        }
         __syncthreads();
         const int kn = kt + 2 * BK;
         const bool more = kn < ke;
@@ -577,16 +608,33 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
       fprintf(stderr, "GEMMLOG %d %d %d lower=%d atri=%d btri=%d inplace=%d cfg=%d part=%s blocks=%u\n", g.M, g.N, g.K,
               g.c_lower, g.a_tri, g.b_tri, g.inplace, TM * 10 + TN, part, blocks);
   };
+  // pacing counters (one per super-tile, at the head of the workspace) for the main part of a long-K
+  // launch in super-tile mode with plain operands
+  // OFF by default: pacing lifts the L2 hit rate of the dominant launch from 36 % to 86 % (fabric reads
+  // 4.8x lower) but not its speed -- the misses are served by the Infinity Cache / HBM at 1.5 TB/s, far from
+  // binding, while waiting for the slowest partner costs 0.3-1 % (M = N = K = 16384: 73.2 unpaced, 73.0 /
+  // 72.6 / 72.2 TFLOP/s paced every 128 / 64 / 32 k-tiles; potrf(65536) 1365 -> 1378 ms).  Kept as a switch
+  // because it is the measured answer to "why is the fabric traffic 20x the algorithmic bytes".
+  static const long pace_on = env_long("GPX_GEMM_PACE", 0);   // development switch
+  static const long pace_kt = env_long("GPX_GEMM_PACE_KT", SYNC_KT);   // development override (a power of two)
+  GemmDesc gp = g;
+  if (pace_on && nsuper != 0 && TM * TN >= 16 && t_ws != nullptr && !g.a_tri && !g.b_tri && !g.inplace &&
+      g.K >= 2 * pace_kt * BK && (size_t)nsuper * sizeof(unsigned) <= t_ws_elems * sizeof(double)) {
+    gp.sync_cnt = reinterpret_cast<unsigned*>(t_ws);
+    gp.sync_kt = (int)pace_kt;
+    if (hipMemsetAsync(gp.sync_cnt, 0, (size_t)nsuper * sizeof(unsigned), s) != hipSuccess) gp.sync_cnt = nullptr;
+  }
   auto launch = [&](dim3 gr, unsigned dyn, unsigned bid0) {
     log_launch(dyn ? "tail" : "main", gr.x);
+    const GemmDesc& gk = dyn ? g : gp;   // (the tail runs one workgroup per CU, unpaced)
     if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_KC)
-      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, gk, tm, tn, nsuper, bid0, order);
     else if (g.a_lay == GPX_LAY_KC && g.b_lay == GPX_LAY_RC)
-      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_KC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, gk, tm, tn, nsuper, bid0, order);
     else if (g.a_lay == GPX_LAY_RC && g.b_lay == GPX_LAY_RC)
-      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_RC, TM, TN>), gr, block, dyn, s, gk, tm, tn, nsuper, bid0, order);
     else
-      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, g, tm, tn, nsuper, bid0, order);
+      hipLaunchKernelGGL((gemm_f64_kernel<GPX_LAY_RC, GPX_LAY_KC, TM, TN>), gr, block, dyn, s, gk, tm, tn, nsuper, bid0, order);
   };
   // Tail of a multi-round launch.  Workgroups are dispatched in id order, 512 live ones per round of
   // the chip.  When the last round(s) hold few live tiles, the slots they land in are the

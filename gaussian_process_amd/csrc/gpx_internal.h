@@ -72,6 +72,10 @@ struct GemmDesc {
   int split_s = 0;
   unsigned split_tile0 = 0;
   double* ws = nullptr;
+  // pacing of the workgroups of a super-tile (filled by gpx_gemm_launch): one zeroed counter per super-tile;
+  // nullptr = none (see gemm_f64_kernel)
+  unsigned* sync_cnt = nullptr;
+  int sync_kt = 128;  // k-tiles between two pacing points (a power of two)
 };
 
 // Workspace of the split-K tail for the calling thread's current handle (set by the C ABI entry points,
