@@ -214,6 +214,15 @@ class DistributedGP:
             g = dist.new_group([p * self.Q + q for p in range(self.P)]) if self.cc else None
             if q == self.q:
                 self.col_group = g
+        # Touch every communicator once, rows first, then columns, the same order on every rank: RCCL builds a
+        # communicator at its first collective (a host-side rendezvous of its members); doing that here keeps
+        # it out of the factorisation, where the first uses are asynchronous and interleaved with kernels.
+        if self.wc:
+            one = self.torch.ones(1, dtype=self.torch.float64, device=getattr(ops, "device", "cpu"))
+            for grp in (self.row_group if self.rc else None, self.col_group if self.cc else None):
+                if grp is not None:
+                    self._all_reduce(one, group=grp)
+            self._all_reduce(one)
         self.n = 0
         self._ws = {}
         self._winv = {}
