@@ -106,7 +106,7 @@ def test_gemm_very_long_k_runs_in_chunks(rt, ta, tb):
 
 # ----------------------------------------------------------------------------- Gram
 @pytest.mark.parametrize("kind,d", [("rbf", 1), ("rbf", 3), ("ard", 2), ("ard", 8), ("ard", 5)])
-@pytest.mark.parametrize("n1,n2", [(1, 1), (15, 50), (129, 257), (300, 300)])
+@pytest.mark.parametrize("n1,n2", [(1, 1), (15, 50), (129, 257), (300, 300), (700, 1537), (1100, 512)])   # the last two: 512-column strips, several row blocks of the packed lower grid
 def test_gram_matches_oracle(rt, kind, d, n1, n2):
     rng = np.random.default_rng(n1 + 7 * n2 + d)
     X1 = rng.uniform(-3, 3, (n1, d))
