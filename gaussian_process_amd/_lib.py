@@ -50,6 +50,7 @@ SIGNATURES = {
     "gpx_grad_trace_slab": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _dp, _dp, _i, _i, _i, _i, _i, _hp]),
     "gpx_gpr_lml_grad": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _dp,
                               _dp, _dp, _hp, _hp]),
+    "gpx_gpr_grad_from_factor": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _dp, _i, _dp, _dp, _dp, _hp]),
     "gpx_gpr_predict": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _dp, _i, _i,
                              _dp, _i, _dp, _dp, _dp, _i, _dp, _i]),
     "gpx_gpr_predict_inv": (_i, [C.c_void_p, _i, _dp, _i, _i, _i, _d, _hp, _d, _dp, _dp, _i, _dp, _i, _i, _dp, _dp,

@@ -645,6 +645,31 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
   return 0;
 }
 
+int gpx_gpr_grad_from_factor(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
+                             const double* beta_host, double* Ky, int ldk, const double* dinv, double* vec,
+                             const double* alpha, double* grad_host) {
+  GPX_REQUIRE(h != nullptr && grad_host != nullptr, "gpr_grad_from_factor: null argument");
+  BetaArg b;
+  int nbeta;
+  GPX_TRY(fill_beta(kind, d, beta_host, b, nbeta));
+  GPX_REQUIRE(n > 0 && X && alpha && vec && dinv && ldx >= d, "gpr_grad_from_factor: bad arguments");
+  GPX_TRY(check_mat("gpr_grad_from_factor: Ky", Ky, ldk, n));
+  GPX_REQUIRE(gpx_aligned16(vec) && gpx_aligned16(dinv), "gpr_grad_from_factor: scratch must be 16-byte aligned");
+  for (int k = 0; k < nbeta; ++k) GPX_REQUIRE(b.b[k] > 0.0, "gpr_grad_from_factor: beta[%d] must be positive", k);
+  DeviceGuard dg(h);
+  hipStream_t s = h->stream;
+  // the second half of gpx_gpr_lml_grad, from the factor an LML-only evaluation left behind
+  double* kdiag = vec + 4L * n;
+  double* sc = red_scalars(h);
+  GPX_TRY(trtri_rec(s, n, Ky, ldk, dinv));
+  GPX_TRY(lauum_upper(s, n, Ky, ldk, kdiag));
+  GPX_TRY(gpx_grad_trace_launch(s, X, ldx, d, nbeta, sigma, b, alpha, Ky, ldk, 0, 0, n, n, h->red, RED_USABLE, sc,
+                                kdiag));
+  double raw[GPX_MAXD + 2];
+  GPX_TRY(fetch(h, sc, raw, 2 + nbeta));
+  return finish_grad(nbeta, sigma, b, raw, grad_host);
+}
+
 int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
                     const double* beta_host, double noise, const double* y, const double* L,
                     int ldl, const double* dinv, const double* Xs, int m, int ldxs, double* V,

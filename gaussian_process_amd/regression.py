@@ -6,7 +6,8 @@ reference class (regression.py:8-76); the arithmetic runs in libgpx:
   predict_with_variance   regression.py:31-44  -> gpx_gpr_lml_grad (factor) + gpx_gpr_predict, or
                                                   gpx_gpr_predict_inv after a gradient evaluation
   log_marginal_likelihood regression.py:46-55  -> gpx_gpr_lml_grad (grad_host = NULL)
-  grad_log_marginal_...   regression.py:57-76  -> gpx_gpr_lml_grad (fused LML + gradient)
+  grad_log_marginal_...   regression.py:57-76  -> gpx_gpr_lml_grad (fused LML + gradient), or
+                                                  gpx_gpr_grad_from_factor after an LML evaluation
 
 Quirks kept: the noise enters as ``sigma * I`` (a variance); ``fit`` returns None; the
 predictive covariance is the full m x m matrix including ``+ sigma * I``; the gradient dict is
@@ -88,6 +89,15 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         ngrad = 2 + len(beta)
         grad = (C.c_double * ngrad)()
         ld = dv["Ky"].shape[1]
+        if st is not None and st["key"] == key and st["has_factor"]:
+            # LML first, gradient second at the same theta (the order of base.py:35-37): go on from the
+            # factor and alpha of the LML evaluation, no second Gram matrix or factorisation
+            rc = rt.lib.gpx_gpr_grad_from_factor(
+                rt.h, kind, ptr(dv["X"]), n, dv["X"].shape[1], self.dim, sigma_k, beta_p, ptr(dv["Ky"]), ld,
+                ptr(dv["dinv"]), ptr(dv["vec"]), ptr(dv["alpha"]), C.cast(grad, C.POINTER(C.c_double)))
+            _lib.check(rc, "gpx_gpr_grad_from_factor")
+            self._state = dict(key=key, lml=st["lml"], grad=np.array(list(grad), dtype=np.float64), has_factor=False)
+            return self._state
         rc = rt.lib.gpx_gpr_lml_grad(
             rt.h, kind, ptr(dv["X"]), n, dv["X"].shape[1], self.dim, sigma_k, beta_p, key[3],
             ptr(dv["y"]), ptr(dv["Ky"]), ld, ptr(dv["dinv"]),

@@ -187,6 +187,14 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
                      double sigma, const double* beta_host, double noise, const double* y,
                      double* Ky, int ldk, double* dinv, double* vec,
                      double* alpha_out, double* a_out, double* lml_host, double* grad_host);
+/* regression.py:57-76 when regression.py:46-55 has just run at the same hyper-parameters (the order of
+ * base.py:35-37): continues from what gpx_gpr_lml_grad(grad_host = NULL) left -- L in the lower triangle of Ky,
+ * its dinv, alpha = Ky^-1 y -- to the gradient, without a second Gram matrix or factorisation.  On exit
+ * Ky, vec[4n, 5n) are as after the fused call (L^-1 lower, Ky^-1 strict upper, its diagonal in vec), so
+ * gpx_gpr_predict_inv applies.  vec: the same 5*n doubles; only [4n, 5n) is written. */
+int gpx_gpr_grad_from_factor(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
+                             const double* beta_host, double* Ky, int ldk, const double* dinv, double* vec,
+                             const double* alpha, double* grad_host);
 /* regression.py:31-44 given the factor L (lower) of Ky and its dinv:
  *   V (n x ldv >= m) scratch, mean (m), cov (m x ldc) = K(Xs,Xs) - V^T V + noise I (full matrix,
  *   or only its lower triangle + mirrored when full_cov=1; full_cov=0 fills only var (m)). */

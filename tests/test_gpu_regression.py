@@ -295,6 +295,62 @@ def test_estimator_keeps_one_matrix_for_factor_inverse_factor_and_inverse():
     assert relerr(mean, mean_o) < TOL and relerr(cov, cov_o) < TOL
 
 
+def test_gradient_after_lml_continues_from_the_factor():
+    """base.py:35-37 asks for the LML first and the gradient second at the same theta.  The second call goes on
+    from the factor and alpha of the first (gpx_gpr_grad_from_factor: no second Gram matrix, no second
+    factorisation) and gives the fused evaluation's numbers bit for bit -- the same kernels on the same data."""
+    import time
+    import torch
+    from gaussian_process_amd import ARD, GaussianProcessRegression
+    n = 3000
+    X, y, Xs, beta = O.synthetic_ard(n, m=50, d=8, seed=21)
+    fused = GaussianProcessRegression(ARD(sigma=0.9, beta=beta), sigma=0.05)
+    fused.fit(X, y)
+    g_f = fused.grad_log_marginal_likelihood()            # fused: Gram, potrf, solves, trtri, lauum, traces
+    two = GaussianProcessRegression(ARD(sigma=0.9, beta=beta), sigma=0.05)
+    two.fit(X, y)
+    lml = two.log_marginal_likelihood()
+    assert two._state["has_factor"] is True and two._state["grad"] is None
+    mean_L = two.predict(Xs)                              # prediction from the factor in between
+    g_t = two.grad_log_marginal_likelihood()
+    assert two._state["has_factor"] is False and two._state["lml"] == lml == fused.log_marginal_likelihood()
+    for k in g_f:
+        assert np.array_equal(g_f[k], g_t[k]), k
+    g_o, _ = O.gpr_grad("ard", X, y, 0.9, beta, 0.05)
+    scale = max(np.abs(v).max() for v in g_o.values())
+    for k in g_o:
+        assert np.abs(g_t[k] - g_o[k]).max() <= 1e-8 * scale, k
+    # the buffer now holds what the fused call leaves: prediction from the inverse factor
+    mean_o, cov_o = O.gpr_predict("ard", X, y, Xs, 0.9, beta, 0.05)
+    mean, cov = two.predict_with_variance(Xs)
+    assert relerr(mean_L, mean_o) < TOL and relerr(mean, mean_o) < TOL and relerr(cov, cov_o) < TOL
+    # a changed theta never takes the continuation
+    two.set_params(sigma=0.06)
+    two.log_marginal_likelihood()
+    two.set_params(sigma=0.07)
+    g7 = two.grad_log_marginal_likelihood()
+    fused.set_params(sigma=0.07)
+    assert np.array_equal(g7["cov__beta"], fused.grad_log_marginal_likelihood()["cov__beta"])
+    # cost: LML then gradient is one evaluation, not an LML-only one plus a fused one
+    n = 8192
+    X, y, _, beta = O.synthetic_ard(n, m=4, d=8, seed=4)
+    gp = GaussianProcessRegression(ARD(sigma=1.0, beta=beta), sigma=0.1)
+    gp.fit(X, y)
+    gp.grad_log_marginal_likelihood()
+
+    def timed(order, sigma):
+        gp.set_params(sigma=sigma)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in order:
+            f()
+        return time.perf_counter() - t0
+
+    t_fused = min(timed([gp.grad_log_marginal_likelihood, gp.log_marginal_likelihood], 0.1 + 1e-7 * i) for i in (1, 2, 3))
+    t_two = min(timed([gp.log_marginal_likelihood, gp.grad_log_marginal_likelihood], 0.1 + 1e-7 * i) for i in (4, 5, 6))
+    assert t_two < 1.15 * t_fused + 1e-3, (t_two, t_fused)
+
+
 def test_threads_and_streams_share_the_device_handle_safely():
     """One gpx handle per GPU (shared reduction scratch, pinned staging, stream binding): estimator
     operations are serialised per device by the runtime's lock, and a change of torch stream orders the

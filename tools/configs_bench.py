@@ -53,7 +53,7 @@ def c3(n=16384, m=4096):
         gp._state = None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        lml = gp.log_marginal_likelihood()
+        lml = gp.log_marginal_likelihood()      # LML first, as base.py:35-37: the gradient goes on from its factor
         g = gp.grad_log_marginal_likelihood()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
