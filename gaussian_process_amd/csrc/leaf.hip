@@ -9,17 +9,20 @@
 // fragment reads); a ragged block is padded with an identity, which factors and inverts to itself.
 //
 //   factorisation, 8 panels of 16 columns:
-//     A  wave 0 factors the 16x16 diagonal tile in registers (lane = row; pivots and multipliers
-//        travel by v_readlane, no LDS, no barrier; 1/sqrt by v_rsq_f64 + 2 Newton steps)
-//     B  one lane per row below the tile: x <- x L_tile^-T by substitution (multipliers are
-//        uniform LDS broadcasts), <= 112 rows
+//     A  wave 0 factors the 16x16 diagonal tile and inverts the factor in registers, four columns at a
+//        time: the 4x4 pivot block is broadcast by v_readlane and factored in uniform registers (1/sqrt by
+//        v_rsq_f64 + one third-order correction), panel scaling and rank-4 updates are single MFMAs
+//        (diag_tile below); no LDS, no barrier
+//     B  the 16-row tiles below the diagonal tile: X <- X W_tile^T on the matrix cores, one tile per wave
 //     C  trailing update T_ij -= P_i P_j^T on the lower 16x16 tiles, v_mfma_f64_16x16x4_f64,
 //        tiles dealt round-robin to the 8 waves
 //     three barriers per panel (24 in all, against one per column = 128 before)
 //   inverse, in place over L, by recursive doubling  inv([A 0; C B]) = [A^-1 0; -B^-1 C A^-1  B^-1]:
 //     level 0: the 8 diagonal tiles by substitution, one wave each
 //     level 1-3: T = C A^-1 stays in the MFMA accumulator registers, whose layout IS the B-operand
-//        fragment layout, so W = -B^-1 T needs no LDS round trip; one wave per tile column.
+//        fragment layout, so W = -B^-1 T needs no LDS round trip; one wave per tile column.  (The levels
+//        are bound by the CU's four matrix pipes, 64 cycles per fp64 MFMA: spreading level 2 and 3 over all
+//        8 waves, two per SIMD, measured the same 12 000 cycles.)
 #include "gpx_internal.h"
 
 namespace {
@@ -56,7 +59,7 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
 #pragma unroll
   for (int it = 0; it < GPX_LEAF_NR; ++it) {
     const double e = fma(-p * r, r, 1.0);          // 1 - p r^2
-    r = fma(r, fma(e, 0.375 * e, 0.5 * e), r);     // r (1 + e/2 + 3 e^2 / 8)
+    r = fma(r, e * fma(e, 0.375, 0.5), r);         // r (1 + e/2 + 3 e^2 / 8)
   }
   return r;
 }
@@ -159,41 +162,83 @@ __device__ void invert_lower(double* S, const double* Wall) {
   LEAF_TICK(33);
 }
 
-// Phase A of panel p, one wave: factor the 16x16 diagonal tile in registers and invert it.
-// Lanes 0-15 hold row r of the tile (v[c] = A[r][c]), lanes 16-31 column r of W = L_tile^-1
-// (v[c] = W[c][r], starting from the identity).  The column sweep of the factorisation,
-// a[c] -= a[j] L[c][j], and of the inversion, w[c] -= w[j] L[c][j], are the SAME instruction on the two
-// lane groups: the tile inverse costs no extra issue slots.  Pivots and multipliers travel by
-// v_readlane from lanes 0-15 (no LDS round trip, no barrier); 1/sqrt by v_rsq_f64 + one correction.
-__device__ __forceinline__ void diag_tile(double* S, double* Wall, int p, int* fail, int lane) {
+// The 16x16 diagonal tile of panel p as a full symmetric matrix in accumulator layout (register r of lane l =
+// element [4r + (l >> 4)][l & 15]); only its lower triangle is valid in S.
+__device__ __forceinline__ v4d load_sym_tile(const double* S, int p0, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  v4d t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    t[r] = S[(p0 + max(i, j)) * LD + p0 + min(i, j)];
+  }
+  return t;
+}
+
+// Phase A of panel p, one wave: factor the 16x16 diagonal tile T and invert the factor, four columns at a
+// time, with the rank-4 work on the matrix core.  T arrives symmetric in accumulator layout, where register b
+// (rows 4b..4b+3 = by symmetry columns 4b..4b+3) IS the A/B operand fragment of column block b.  Per block b:
+//   1  the 4x4 diagonal block is broadcast (10 v_readlane pairs) and every lane factors it redundantly in
+//      uniform registers; lane group g = l >> 4 then solves for column g of its inverse W_bb (4 values);
+//   2  P^T = W_bb T[rows of b] and X_b = W_bb E[rows of b]: one MFMA each, with W_bb padded to 16x4 as the
+//      A operand -- register 0 of the result is the scaled panel L[:, 4b + g] (rows of the inverse L^-1
+//      resp.) already in fragment layout;
+//   3  T -= P P^T and E -= P X_b: one MFMA each (E starts as the identity and ends as nothing: its rows
+//      leave as X_b, the rows of L_tile^-1).  (Issuing the E half of block b inside block b + 1's pivot chain,
+//      pinned with sched_barriers, measured 4 % slower per tile: left in program order.)
+// Rows / columns of T and E in front of the current block fill with garbage and are never read again.
+// The serial chain is 4 x (4 pivots + 2 MFMAs) instead of 16 pivots + 120 dependent v_readlane broadcasts
+// (6000 -> 4100 cycles per tile, 8 tiles on the critical path of every leaf: about 150 dependent fp64 VALU
+// instructions and four 64-cycle MFMAs per block).
+__device__ __forceinline__ void diag_tile(double* S, double* Wall, int p, int* fail, int lane, v4d T) {
   const int p0 = p * TS;
   double* Wt = Wall + p * TS * WS;
-  const int r = lane & 15;
-  const bool inv = (lane & 16) != 0;
-  double v[TS];
+  const int g = lane >> 4, i = lane & 15;
+  v4d E;
 #pragma unroll
-  for (int c = 0; c < TS; ++c) {
-    const double a = S[(p0 + r) * LD + p0 + c];
-    v[c] = inv ? (c == r ? 1.0 : 0.0) : a;
-  }
+  for (int r = 0; r < 4; ++r) E[r] = (4 * r + g == i) ? 1.0 : 0.0;
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  const double e0 = g == 0 ? 1.0 : 0.0, e1 = g == 1 ? 1.0 : 0.0, e2 = g == 2 ? 1.0 : 0.0, e3 = g == 3 ? 1.0 : 0.0;
+  const double m0 = i == 0 ? 1.0 : 0.0, m1 = i == 1 ? 1.0 : 0.0, m2 = i == 2 ? 1.0 : 0.0, m3 = i == 3 ? 1.0 : 0.0;
   int bad = 0;
 #pragma unroll
-  for (int j = 0; j < TS; ++j) {
-    const double d = readlane_f64(v[j], j);
-    if (!(d > 0.0) && bad == 0) bad = p0 + j + 1;
-    v[j] *= rsqrt_nr(d);                         // L[r][j] (row j: d / sqrt(d) = L_jj)  |  W[j][r] final
-#pragma unroll
-    for (int c = j + 1; c < TS; ++c) {
-      const double lcj = readlane_f64(v[j], c);  // L[c][j]
-      v[c] = fma(-v[j], lcj, v[c]);
+  for (int b = 0; b < 4; ++b) {
+    const double tb = T[b];
+    // element (row 4b + gr, column 4b + c) of the tile sits in lane 16 gr + 4b + c of register b
+    const double a00 = readlane_f64(tb, 4 * b);
+    const double a10 = readlane_f64(tb, 16 + 4 * b), a11 = readlane_f64(tb, 16 + 4 * b + 1);
+    const double a20 = readlane_f64(tb, 32 + 4 * b), a21 = readlane_f64(tb, 32 + 4 * b + 1),
+                 a22 = readlane_f64(tb, 32 + 4 * b + 2);
+    const double a30 = readlane_f64(tb, 48 + 4 * b), a31 = readlane_f64(tb, 48 + 4 * b + 1),
+                 a32 = readlane_f64(tb, 48 + 4 * b + 2), a33 = readlane_f64(tb, 48 + 4 * b + 3);
+    const double r0 = rsqrt_nr(a00);
+    const double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
+    const double d1 = fma(-l10, l10, a11);
+    const double r1 = rsqrt_nr(d1);
+    const double l21 = fma(-l20, l10, a21) * r1, l31 = fma(-l30, l10, a31) * r1;
+    const double d2 = fma(-l21, l21, fma(-l20, l20, a22));
+    const double r2 = rsqrt_nr(d2);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * r2;
+    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33)));
+    const double r3 = rsqrt_nr(d3);
+    // one test per block on the common path: a non-positive (or NaN) pivot makes every later one NaN, and
+    // fmin skips NaNs, so the minimum is the offending pivot (or NaN if the input was)
+    if (!(fmin(fmin(a00, d1), fmin(d2, d3)) > 0.0) && bad == 0)
+      bad = p0 + 4 * b + (!(a00 > 0.0) ? 1 : (!(d1 > 0.0) ? 2 : (!(d2 > 0.0) ? 3 : 4)));
+    // column g of W_bb = L_bb^-1 by substitution (exact zeros above the diagonal)
+    const double w0 = e0 * r0;
+    const double w1 = fma(-l10, w0, e1) * r1;
+    const double w2 = fma(-l21, w1, fma(-l20, w0, e2)) * r2;
+    const double w3 = fma(-l32, w2, fma(-l31, w1, fma(-l30, w0, e3))) * r3;
+    const double wsel = fma(m3, w3, fma(m2, w2, fma(m1, w1, m0 * w0)));   // W_bb[i][g], 16x4 padded; branch-free
+    const double pcol = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, tb, zero, 0, 0, 0)[0];     // L[i][4b + g]
+    const double xrow = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, E[b], zero, 0, 0, 0)[0];   // Linv[4b + g][i]
+    if (b < 3) {
+      T = __builtin_amdgcn_mfma_f64_16x16x4f64(-pcol, pcol, T, 0, 0, 0);
+      E = __builtin_amdgcn_mfma_f64_16x16x4f64(-pcol, xrow, E, 0, 0, 0);
     }
-  }
-  if (lane < TS) {
-#pragma unroll
-    for (int c = 0; c < TS; ++c) S[(p0 + r) * LD + p0 + c] = c <= r ? v[c] : 0.0;
-  } else if (lane < 2 * TS) {
-#pragma unroll
-    for (int c = 0; c < TS; ++c) Wt[c * WS + r] = v[c];   // W[c][r], zero for c < r
+    S[(p0 + i) * LD + p0 + 4 * b + g] = i >= 4 * b + g ? pcol : 0.0;
+    Wt[(4 * b + g) * WS + i] = i <= 4 * b + g ? xrow : 0.0;
   }
   if (lane == 0 && bad != 0 && *fail == 0) *fail = bad;
 }
@@ -210,7 +255,7 @@ __device__ __forceinline__ void diag_tile(double* S, double* Wall, int p, int* f
 // Two barriers per panel.
 __device__ void factor_lower(double* S, double* Wall, int* fail) {
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  if (wid == 0) diag_tile(S, Wall, 0, fail, lane);
+  if (wid == 0) diag_tile(S, Wall, 0, fail, lane, load_sym_tile(S, 0, lane));
   __syncthreads();
   LEAF_TICK(2);
   for (int p = 0; p + 1 < NT; ++p) {
@@ -231,16 +276,11 @@ __device__ void factor_lower(double* S, double* Wall, int* fail) {
     LEAF_TICK(3 + 2 * p);
     if (wid == 0) {
       const int tn = p + 1;
-      double* pc = S + (tn * TS + (lane >> 4)) * LD + tn * TS + (lane & 15);
       const double* pa = S + (tn * TS + (lane & 15)) * LD + p0 + (lane >> 4);
-      v4d acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = pc[4 * r * LD];
+      v4d acc = load_sym_tile(S, tn * TS, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * r], pa[4 * r], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pc[4 * r * LD] = acc[r];
-      diag_tile(S, Wall, tn, fail, lane);      // same wave: its LDS writes above are ordered before these reads
+      diag_tile(S, Wall, tn, fail, lane, acc);  // the updated tile goes on in registers, symmetric
     } else {
       const int m = NT - p - 1, ntile = m * (m + 1) / 2;   // tile 0 of the triangle is wave 0's
       double* pc[4];
