@@ -46,11 +46,16 @@ def main(args, rank, local_rank, world, cpu_baseline=None, traffic=None):
                        force_collectives=world == 1)   # on one rank the collectives still run (groups of one)
     sigma, noise = 1.0, 0.1
 
+    phase_log = os.environ.get("GPX_GEMM_LOG") is not None     # development: tools/dist_trace.sh joins the launch log
+
     def step(marks):
         def mark(name):
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             marks.append((name, e))
+            if phase_log:
+                import sys
+                print("PHASE after-" + name, file=sys.stderr, flush=True)
         mark("start")
         gp.build_gram()
         mark("gram")
