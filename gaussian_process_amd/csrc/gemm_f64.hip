@@ -177,7 +177,7 @@ struct Tile {
 // work of a tile depends on its row or column; the heavy ones go first so that the last round of the
 // launch holds only light tiles (longest-processing-time-first), and at any moment all XCDs work on
 // tiles of similar weight.
-enum { ORD_ROWS_SKEWED = 0, ORD_COLS_ASC = 1, ORD_COLS_DESC = 2, ORD_ROWS_DESC = 3 };
+enum { ORD_ROWS_SKEWED = 0, ORD_COLS_ASC = 1, ORD_COLS_DESC = 2, ORD_ROWS_DESC = 3, ORD_ROWS_ASC_TRI = 4 };
 
 __host__ __device__ __forceinline__ void super_coords(unsigned st, int tiles_m, int tiles_n, int order, unsigned& sr,
                                                       unsigned& sc) {
@@ -209,6 +209,13 @@ __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower
       bi = (int)r;
       bj = (int)(bid - r * (r + 1) / 2);
     } else {
+      // One round of the chip (257..512 tiles, two workgroups per CU) with a triangular operand: the work of a
+      // tile grows linearly along the rows (or columns), and ids c and 256 + c share a CU.  The second 256
+      // ids walk the tiles backwards from the last one, so that every CU gets a light and a heavy tile
+      // (row-major ids pair row r with row r + 8 of 16: the slowest CU holds 24/17 of the mean -- a 2048 x 4096
+      // product with a triangular 2048-operand took 373 us against 245 us balanced).
+      const unsigned nt = (unsigned)tiles_m * (unsigned)tiles_n;
+      if (order != ORD_ROWS_SKEWED && nt > 256 && nt <= 512 && bid >= 256) bid = nt - 1 - (bid - 256);
       bi = (int)(bid / (unsigned)tiles_n);
       bj = (int)(bid % (unsigned)tiles_n);
     }
@@ -613,6 +620,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
   if (!g.c_lower && lpt) {
     if (g.b_tri) order = g.b_lay == GPX_LAY_RC ? ORD_COLS_ASC : ORD_COLS_DESC;      // k >= j0  |  k < j0 + BN
     else if (g.a_tri && g.a_lay == GPX_LAY_KC) order = ORD_ROWS_DESC;               // k < i0 + BM
+    else if (g.a_tri) order = ORD_ROWS_ASC_TRI;   // k >= i0: heavy rows come first anyway; marks the operand triangular
   }
   static const bool log_shapes = getenv("GPX_GEMM_LOG") != nullptr;   // development: one line per kernel launch
   auto log_launch = [&](const char* part, unsigned blocks) {
