@@ -118,7 +118,7 @@ def test_bad_inputs_raise_like_reference():
         gp.fit(np.zeros(4), np.zeros(4))
 
 
-@pytest.mark.parametrize("n", [8192])
+@pytest.mark.parametrize("n", [8192, 16384])      # 16384: BASELINE configs[2] at its exact size
 def test_large_size_properties(n):
     """Beyond the sizes the reference can run: size-independent properties.
     ||Ky alpha - y|| / ||y||, ||L L^T - Ky||_F / ||Ky||_F on sampled rows, LML against the oracle
