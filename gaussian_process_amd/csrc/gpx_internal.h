@@ -107,6 +107,9 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int n
 // trsv.hip: x <- L^-1 x (trans 0) / L^-T x (trans 1) for one strided vector
 int gpx_trsv_launch(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv, double* x,
                     long incx, double* red, size_t red_elems);
+// y = W x (trans = 0) or W^T x (trans = 1) for a lower-triangular W (only j <= i read); y must not alias x
+int gpx_trmv_lower_launch(hipStream_t s, int trans, int n, const double* W, long ldw, const double* x, double* y,
+                          double* red, size_t red_elems);
 
 // ep.hip: one sweep of site updates in the given order, rank-1 updates delayed GPX_EP_BLOCK at a time;
 // work: gpx_ep_sweep_work_elems_impl(n) device doubles

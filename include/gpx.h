@@ -119,6 +119,11 @@ int gpx_syrk_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double* 
  * transa/transb: 0 = stored as op, 1 = stored transposed. */
 int gpx_gemm(gpx_handle* h, int transa, int transb, int M, int N, int K, double alpha,
              const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc);
+/* y = W x (trans = 0) or y = W^T x (trans = 1) for a lower-triangular n x n matrix W (only W[i][j], j <= i, is
+ * read; what lies above the diagonal may be anything); y must not alias x.  With W = L^-1 from gpx_trtri these
+ * are a = L^-1 y and alpha = L^-T a of regression.py:50,61 as two streaming passes without a dependent chain:
+ * what the fused gradient evaluation uses in place of the two triangular solves. */
+int gpx_trmv(gpx_handle* h, int trans, int n, const double* W, int ldw, const double* x, double* y);
 /* Out (n x m) = L B (trans = 0) or L^T B (trans = 1) for a lower-triangular n x n matrix L (only its
  * lower triangle is read) and B n x m; Out must not alias B.  Sampling f = L z from the GP prior /
  * posterior with the factor gpx_potrf produced -- the O(n^2) replacement for numpy's SVD-based

@@ -370,6 +370,23 @@ def test_trmm_lower_times_matrix(rt, n, m):
     assert relerr(down(rt, dO, n, m), L.T @ B) < 1e-13
 
 
+@pytest.mark.parametrize("n", [1, 2, 100, 128, 129, 1000, 2047, 4096, 5001, 16500])
+def test_trmv_lower_times_vector(rt, n):
+    """y = W x and y = W^T x reading only the lower triangle of W (NaN above it): the streaming replacement of the
+    two vector solves once the gradient pass holds W = L^-1."""
+    rng = np.random.default_rng(n)
+    W = np.tril(rng.standard_normal((n, n)))
+    x = rng.standard_normal(n)
+    dW = up(rt, W + np.triu(np.full((n, n), np.nan), 1))
+    dx, dy = rt.upload_vector(x), rt.vector(n)
+    ok(rt.lib.gpx_trmv(rt.h, 0, n, P(dW), dW.shape[1], P(dx), P(dy)))
+    assert relerr(rt.download(dy[:n]), W @ x) < 1e-13
+    ok(rt.lib.gpx_trmv(rt.h, 1, n, P(dW), dW.shape[1], P(dx), P(dy)))
+    assert relerr(rt.download(dy[:n]), W.T @ x) < 1e-13
+    with pytest.raises(Exception):
+        ok(rt.lib.gpx_trmv(rt.h, 0, n, P(dW), dW.shape[1], P(dx), P(dx)))
+
+
 def test_grad_trace_row_bands_give_the_same_sums():
     """When the per-workgroup partials of a large n x d would not fit the reduction scratch the launch is
     split into row bands whose sums accumulate; forced here with one block row per band (development

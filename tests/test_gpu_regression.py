@@ -298,7 +298,8 @@ def test_estimator_keeps_one_matrix_for_factor_inverse_factor_and_inverse():
 def test_gradient_after_lml_continues_from_the_factor():
     """base.py:35-37 asks for the LML first and the gradient second at the same theta.  The second call goes on
     from the factor and alpha of the first (gpx_gpr_grad_from_factor: no second Gram matrix, no second
-    factorisation) and gives the fused evaluation's numbers bit for bit -- the same kernels on the same data."""
+    factorisation) and gives the fused evaluation's numbers to rounding: the same factor, inverse and traces; only
+    alpha comes from two solves there and from two multiplies by L^-1 in the fused call."""
     import time
     import torch
     from gaussian_process_amd import ARD, GaussianProcessRegression
@@ -313,11 +314,12 @@ def test_gradient_after_lml_continues_from_the_factor():
     assert two._state["has_factor"] is True and two._state["grad"] is None
     mean_L = two.predict(Xs)                              # prediction from the factor in between
     g_t = two.grad_log_marginal_likelihood()
-    assert two._state["has_factor"] is False and two._state["lml"] == lml == fused.log_marginal_likelihood()
-    for k in g_f:
-        assert np.array_equal(g_f[k], g_t[k]), k
+    assert two._state["has_factor"] is False and two._state["lml"] == lml
+    assert abs(lml - fused.log_marginal_likelihood()) <= 1e-13 * abs(lml)
     g_o, _ = O.gpr_grad("ard", X, y, 0.9, beta, 0.05)
     scale = max(np.abs(v).max() for v in g_o.values())
+    for k in g_f:
+        assert np.abs(g_f[k] - g_t[k]).max() <= 1e-11 * scale, k
     for k in g_o:
         assert np.abs(g_t[k] - g_o[k]).max() <= 1e-8 * scale, k
     # the buffer now holds what the fused call leaves: prediction from the inverse factor
@@ -330,7 +332,7 @@ def test_gradient_after_lml_continues_from_the_factor():
     two.set_params(sigma=0.07)
     g7 = two.grad_log_marginal_likelihood()
     fused.set_params(sigma=0.07)
-    assert np.array_equal(g7["cov__beta"], fused.grad_log_marginal_likelihood()["cov__beta"])
+    assert np.array_equal(g7["cov__beta"], fused.grad_log_marginal_likelihood()["cov__beta"])   # both fused
     # cost: LML then gradient is one evaluation, not an LML-only one plus a fused one
     n = 8192
     X, y, _, beta = O.synthetic_ard(n, m=4, d=8, seed=4)

@@ -40,3 +40,18 @@ for trans in (0, 1):
     r = y[:n] - b[:, 0]
     print("trsv trans=%d n=%d: %.3f ms  (%.0f GB/s of L's triangle)  residual %.2e" %
           (trans, n, ms, 4.0 * n * n / ms / 1e6, (r.norm() / b[:, 0].norm()).item()), flush=True)
+# the streaming counterpart once W = L^-1 is there: y = W x, y = W^T x (timed on the same triangle)
+xv, yv = rt.vector(n), rt.vector(n)
+xv[:n] = b[:, 0]
+for trans in (0, 1):
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.gpx_trmv(rt.h, trans, n, P(L), ld, P(xv), P(yv)), "trmv")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+    ref = rt.vector(n)
+    _lib.check(lib.gpx_gemv(rt.h, 1 if trans else 0, n, n, P(L), ld, P(xv), P(ref)), "gemv")   # L is stored with zeros above
+    print("trmv trans=%d n=%d: %.3f ms  (%.0f GB/s of W's triangle)  difference to the full product %.2e" %
+          (trans, n, ms, 4.0 * n * n / ms / 1e6, ((yv[:n] - ref[:n]).norm() / ref[:n].norm()).item()), flush=True)
