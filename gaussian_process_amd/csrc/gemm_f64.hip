@@ -241,8 +241,16 @@ __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower
 }
 
 template <int ALAY, int BLAY, int TM, int TN>
-__global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 4))) void gemm_f64_kernel(const GemmDesc g, int tiles_m, int tiles_n,
+__global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 4))) void gemm_f64_kernel(const GemmDesc gin, int tiles_m, int tiles_n,
                                                                  unsigned nsuper, unsigned bid0, int order) {
+  GemmDesc g = gin;
+  if (gin.batch > 1) {   // uniform: this workgroup's product of the batch
+    const long z = blockIdx.y;
+    g.A += z * gin.stride_a;
+    g.B += z * gin.stride_b;
+    g.D += z * gin.stride_d;
+    if (g.Cin != nullptr) g.Cin += z * gin.stride_d;
+  }
   constexpr int BM = 32 * TM, BN = 32 * TN;
   typedef Tile<ALAY, BM> TA;
   typedef Tile<BLAY, BN> TB;
@@ -614,6 +622,8 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     nsuper = 0;
     grid = dim3((unsigned)ntiles);
   }
+  const bool batched = g.batch > 1;   // grid.y: no separate tail, no split-K, no pacing (one launch, one part)
+  if (batched) grid.y = (unsigned)g.batch;
   // heavy tiles first (see super_coords): which side is heavy follows from how gemm_f64_kernel clips k
   int order = ORD_ROWS_SKEWED;
   static const bool lpt = getenv("GPX_GEMM_LPT") == nullptr || atoi(getenv("GPX_GEMM_LPT")) != 0;   // development switch
@@ -638,7 +648,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
   static const long pace_on = env_long("GPX_GEMM_PACE", 0);   // development switch
   static const long pace_kt = env_long("GPX_GEMM_PACE_KT", SYNC_KT);   // development override (a power of two)
   GemmDesc gp = g;
-  if (pace_on && nsuper != 0 && TM * TN >= 16 && t_ws != nullptr && !g.a_tri && !g.b_tri && !g.inplace &&
+  if (pace_on && !batched && nsuper != 0 && TM * TN >= 16 && t_ws != nullptr && !g.a_tri && !g.b_tri && !g.inplace &&
       g.K >= 2 * pace_kt * BK && (size_t)nsuper * sizeof(unsigned) <= t_ws_elems * sizeof(double)) {
     gp.sync_cnt = reinterpret_cast<unsigned*>(t_ws);
     gp.sync_kt = (int)pace_kt;
@@ -664,7 +674,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
   // launched separately with enough dynamic LDS that only ONE workgroup fits per CU.
   unsigned main_ids = grid.x;
   const long rem = ntiles % 512;   // live tiles beyond the last full round
-  if (nsuper != 0 && TM * TN >= 16 && rem > 0 && rem <= 256 && tail_split_enabled()) {
+  if (!batched && nsuper != 0 && TM * TN >= 16 && rem > 0 && rem <= 256 && tail_split_enabled()) {
     // whole trailing 512-id chunks (8 super-tiles) only: a finer cut was measured and lost -- where the
     // main part does not end on a chunk boundary its workgroups do not finish together, and the tail
     // overlaps with them better inside one launch
@@ -678,7 +688,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     }
     if (live == rem) main_ids = chunk * 512;
   }
-  if (packed && ntiles > 512 && rem > 0 && rem <= 256 && tail_split_enabled()) {
+  if (!batched && packed && ntiles > 512 && rem > 0 && rem <= 256 && tail_split_enabled()) {
     // packed ids: the tail is simply the last `rem` tiles.  Few of them and a long K: split K over
     // several workgroups per tile (one workgroup per CU, all CUs busy, each at full MFMA rate), partial
     // tiles into the workspace, summed in a fixed order.  Otherwise one workgroup per CU as below.
@@ -732,6 +742,8 @@ void gpx_gemm_set_workspace(double* ws, size_t elems) {
 int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   if (g.M <= 0 || g.N <= 0) return 0;
   GPX_REQUIRE(g.K >= 0, "gemm: negative K");
+  GPX_REQUIRE(g.batch >= 1 && g.batch <= 65535, "gemm: batch out of range");
+  GPX_REQUIRE(g.batch == 1 || (!g.inplace && !g.c_upper && g.split_s <= 1), "gemm: batched launches are plain products");
   GPX_REQUIRE(g.A && g.B && g.D, "gemm: null operand");
   GPX_REQUIRE(g.beta == 0.0 || g.Cin, "gemm: beta != 0 needs Cin");
   GPX_REQUIRE(!g.c_upper || (g.c_lower && g.diag_out && g.M == g.N && g.beta == 0.0),
@@ -751,7 +763,7 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
     const char* e = getenv("GPX_GEMM_KCHUNK");   // development override; 0 disables
     return e ? atol(e) : 8192L;
   }();
-  if (kchunk > 0 && g.K >= 2 * kchunk && !g.a_tri && !g.b_tri && !g.inplace && !g.c_upper && g.split_s <= 1 &&
+  if (kchunk > 0 && g.batch <= 1 && g.K >= 2 * kchunk && !g.a_tri && !g.b_tri && !g.inplace && !g.c_upper && g.split_s <= 1 &&
       (long)g.M * g.N >= 4096L * 4096L) {
     GemmDesc c = g;
     for (int k0 = 0; k0 < g.K; k0 += c.K) {
@@ -766,7 +778,7 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   }
   // 128 x 128 tiles unless that leaves most of the 256 CUs (2 workgroups each) idle.  In-place
   // launches (D aliases an operand) rely on one workgroup owning a whole operand panel: 128 only.
-  const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.c_lower ? 2 : 1);
+  const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.c_lower ? 2 : 1) * (g.batch > 1 ? g.batch : 1);
   // In-place right-multiplies (D aliases A, N <= 128) with few rows: 32-row tiles, still 128 wide, so
   // that a 128 x 128 x 128 leaf solve is spread over 4 CUs instead of being one CU's 13.7 us of MFMA
   // time.  (When D aliases B the workgroup must own all K = M <= 128 rows: 128-row tiles only.)

@@ -159,8 +159,41 @@ int potrf_rec(hipStream_t s, int n, double* A, long lda, double* dinv, int* info
 // [0, n1) x columns [n1, n) of the same square, never referenced by a lower-triangular consumer -- holds
 // T^T for T = L21 W11, so the inverse needs no second buffer (every recursion level uses the upper-right
 // block of its own square; they are disjoint).
+// The same inversion for a block whose order is a power of two times 128, level by level instead of node
+// by node: the 128-block inverses go in with one copy launch, then for block size sz = 128, 256, ... ALL
+// the 2 sz-blocks of the level form their off-diagonal part W21 = -W22 L21 W11 in two batched launches
+// (grid.y = block).  Node by node an n = 4096 block costs 62 + 32 launches of ~10 us fixed cost each for
+// 23 Gflop (1.4 ms); level by level 11 launches.
+static const int TRTRI_LEVELS_MAX = [] {
+  const char* e = getenv("GPX_TRTRI_LEVELS_MAX");   // development override; 0 = node by node everywhere
+  return e ? atoi(e) : 4096;
+}();
+
+int trtri_levels(hipStream_t s, int n, double* L, long ldl, const double* dinv) {
+  GPX_TRY(gpx_copy_dinv_to_diag_batched(s, n / NB, dinv, L, ldl));
+  for (int sz = NB; sz < n; sz *= 2) {
+    const int batch = n / (2 * sz);
+    const long stride = 2L * sz * (ldl + 1);
+    double* L21 = L + (long)sz * ldl;
+    double* L22 = L21 + sz;
+    double* Tt = L + sz;
+    GemmDesc g1 = mk(L, ldl, GPX_LAY_RC, L21, ldl, GPX_LAY_KC, nullptr, 0, Tt, ldl, sz, sz, sz, 1.0, 0.0);
+    g1.a_tri = 1;
+    g1.batch = batch;
+    g1.stride_a = g1.stride_b = g1.stride_d = stride;
+    GPX_TRY(gpx_gemm_launch(s, g1));
+    GemmDesc g2 = mk(L22, ldl, GPX_LAY_KC, Tt, ldl, GPX_LAY_KC, nullptr, 0, L21, ldl, sz, sz, sz, -1.0, 0.0);
+    g2.a_tri = 1;
+    g2.batch = batch;
+    g2.stride_a = g2.stride_b = g2.stride_d = stride;
+    GPX_TRY(gpx_gemm_launch(s, g2));
+  }
+  return 0;
+}
+
 int trtri_rec(hipStream_t s, int n, double* L, long ldl, const double* dinv) {
   if (n <= NB) return gpx_copy_dinv_to_diag(s, n, dinv, L, ldl);
+  if (n <= TRTRI_LEVELS_MAX && n % NB == 0 && ((n / NB) & (n / NB - 1)) == 0) return trtri_levels(s, n, L, ldl, dinv);
   const int n1 = split_point(n), n2 = n - n1;
   double* L21 = L + (long)n1 * ldl;
   double* L22 = L21 + n1;

@@ -76,6 +76,11 @@ struct GemmDesc {
   // nullptr = none (see gemm_f64_kernel)
   unsigned* sync_cnt = nullptr;
   int sync_kt = 128;  // k-tiles between two pacing points (a power of two)
+  // batch of independent products of the same shape in ONE launch (grid.y): operand z starts z * stride_x
+  // elements after operand 0.  The levels of the blocked triangular inversion: all diagonal blocks of one
+  // size are independent, and at the small sizes a launch per block is launch-latency bound.
+  int batch = 1;
+  long stride_a = 0, stride_b = 0, stride_d = 0;   // (Cin, when given, moves with D)
 };
 
 // Workspace of the split-K tail for the calling thread's current handle (set by the C ABI entry points,
@@ -90,6 +95,8 @@ int gpx_leaf_potf2_inv(hipStream_t s, int nb, double* A, long lda, double* dinv_
                        int global_off);
 int gpx_leaf_diag_inv_batched(hipStream_t s, int n, const double* L, long ldl, double* dinv);
 int gpx_copy_dinv_to_diag(hipStream_t s, int nb, const double* dinv_blk, double* L, long ldl);
+// the same for nblk consecutive full 128 x 128 diagonal blocks in one launch
+int gpx_copy_dinv_to_diag_batched(hipStream_t s, int nblk, const double* dinv, double* L, long ldl);
 
 // gram.hip
 struct BetaArg { double b[GPX_MAXD]; };

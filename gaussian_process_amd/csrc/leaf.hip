@@ -420,6 +420,13 @@ __global__ void copy_dinv_kernel(int nb, const double* dinv, double* L, long ldl
   L[(long)i * ldl + j] = dinv[i * NB + j];  // dinv already has zeros above the diagonal
 }
 
+__global__ void copy_dinv_batched_kernel(const double* dinv, double* L, long ldl) {
+  const int blk = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. 128 * 128 - 1
+  const int i = e >> 7, j = e & 127;
+  L[((long)blk * NB + i) * ldl + (long)blk * NB + j] = dinv[(size_t)blk * NB * NB + e];
+}
+
 }  // namespace
 
 int gpx_leaf_potf2_inv(hipStream_t s, int nb, double* A, long lda, double* dinv_blk, int* info_dev,
@@ -440,6 +447,12 @@ int gpx_leaf_diag_inv_batched(hipStream_t s, int n, const double* L, long ldl, d
 int gpx_copy_dinv_to_diag(hipStream_t s, int nb, const double* dinv_blk, double* L, long ldl) {
   const int tot = nb * nb;
   hipLaunchKernelGGL(copy_dinv_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, nb, dinv_blk, L, ldl);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+int gpx_copy_dinv_to_diag_batched(hipStream_t s, int nblk, const double* dinv, double* L, long ldl) {
+  hipLaunchKernelGGL(copy_dinv_batched_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, s, dinv, L, ldl);
   GPX_HIP(hipGetLastError());
   return 0;
 }

@@ -152,7 +152,7 @@ def test_gram_dtheta_matches_oracle(rt):
 
 
 # ----------------------------------------------------------------------------- Cholesky family
-@pytest.mark.parametrize("n", [1, 2, 15, 100, 128, 129, 255, 300, 1000, 2050, 4100, 5000])
+@pytest.mark.parametrize("n", [1, 2, 15, 100, 128, 129, 255, 256, 300, 1000, 1024, 2050, 4096, 4100, 5000, 8192])   # 256 / 1024 / 4096 / 8192: the inversion goes level by level (batched launches)
 def test_potrf_trsm_trtri_lauum(rt, n):
     A = spd(n, n)
     dA = up(rt, A)
