@@ -214,8 +214,7 @@ __device__ __forceinline__ bool block_coords(int tiles_m, int tiles_n, int lower
       // ids walk the tiles backwards from the last one, so that every CU gets a light and a heavy tile
       // (row-major ids pair row r with row r + 8 of 16: the slowest CU holds 24/17 of the mean -- a 2048 x 4096
       // product with a triangular 2048-operand took 373 us against 245 us balanced).
-      const unsigned nt = (unsigned)tiles_m * (unsigned)tiles_n;
-      if (order != ORD_ROWS_SKEWED && nt > 256 && nt <= 512 && bid >= 256) bid = nt - 1 - (bid - 256);
+      // (the remap itself is applied by the kernel before this call: it also serves packed lower launches)
       bi = (int)(bid / (unsigned)tiles_n);
       bj = (int)(bid % (unsigned)tiles_n);
     }
@@ -263,6 +262,11 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
     part = (int)(bid % (unsigned)g.split_s);
     bid = g.split_tile0 + bid / (unsigned)g.split_s;
   }
+  // light / heavy pairing (see block_coords): this launch is one round of the chip, one block per tile, and the
+  // tiles' work falls or rises monotonically with the id (a triangular operand)
+  if (nsuper == 0 && order != ORD_ROWS_SKEWED && g.split_s <= 1 && bid0 == 0 && gridDim.x > 256 && gridDim.x <= 512 &&
+      bid >= 256)
+    bid = gridDim.x - 1 - (bid - 256);
   if (!block_coords(tiles_m, tiles_n, g.c_lower, nsuper, bid, order, bi, bj)) return;
   // Pacing (plain operands, super-tile mode, long K).  The 64 workgroups of a super-tile share 8 + 8 operand
   // panels through their XCD's 4 MiB L2, which holds a window of only 16 k-tiles of those panels; nothing
@@ -632,6 +636,9 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     else if (g.a_tri && g.a_lay == GPX_LAY_KC) order = ORD_ROWS_DESC;               // k < i0 + BM
     else if (g.a_tri) order = ORD_ROWS_ASC_TRI;   // k >= i0: heavy rows come first anyway; marks the operand triangular
   }
+  // lower launches are enumerated row by row; with a triangular operand the work per tile changes monotonically
+  // along that order (lauum: k >= i0), which is all the one-round pairing needs to know
+  if (g.c_lower && lpt && (g.a_tri || g.b_tri)) order = ORD_ROWS_ASC_TRI;
   static const bool log_shapes = getenv("GPX_GEMM_LOG") != nullptr;   // development: one line per kernel launch
   auto log_launch = [&](const char* part, unsigned blocks) {
     if (log_shapes)
