@@ -176,6 +176,13 @@ static int chunk_rows(int n, int m, size_t red_elems) {
   return rows;
 }
 
+// do the partial sums of the transposed n x m product fit a scratch of red_elems doubles?
+bool gpx_gemv_partials_fit(int n, int m, size_t red_elems) {
+  if (n <= 0 || m <= 0) return true;
+  const int rows = chunk_rows(n, m, red_elems);
+  return (size_t)((n + rows - 1) / rows) * m <= red_elems;
+}
+
 int gpx_logdet_launch(hipStream_t s, int n, const double* L, long ldl, double*, double* out_dev) {
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, s, n, L, ldl, out_dev);
   GPX_HIP(hipGetLastError());

@@ -326,6 +326,7 @@ int gpx_destroy(gpx_handle* h) {
   if (h->info_dev) (void)hipFree(h->info_dev);
   if (h->gemm_ws) (void)hipFree(h->gemm_ws);
   if (h->host_pin) (void)hipHostFree(h->host_pin);
+  gpx_gemm_set_workspace(nullptr, 0);   // the thread's split-K workspace pointed into this handle
   delete h;
   return 0;
 }
@@ -534,8 +535,10 @@ int gpx_gemv_static(gpx_handle* h, int trans, int n, int m, const double* A, int
                     double* y) {
   GPX_REQUIRE(h != nullptr && A && x && y, "gemv_static: null argument");
   GPX_REQUIRE(n >= 0 && m >= 0 && lda >= m, "gemv_static: bad shape (n %d, m %d, lda %d)", n, m, lda);
-  GPX_REQUIRE((size_t)m <= GPX_STATIC_SCRATCH_ELEMS && n <= (1 << 28),
-              "gemv_static: %d x %d exceeds the static scratch (m <= %zu, n <= 2^28); use gpx_gemv", n, m,
+  // the real limit: the partial sums of the transposed product (ceil(n / rows) chunks of m doubles, rows = 256
+  // doubled up to 2^20) must fit the array; the plain product uses no scratch at all
+  GPX_REQUIRE(!trans || gpx_gemv_partials_fit(n, m, GPX_STATIC_SCRATCH_ELEMS),
+              "gemv_static: %d x %d exceeds the static scratch (ceil(n / 2^20) * m <= %zu doubles); use gpx_gemv", n, m,
               GPX_STATIC_SCRATCH_ELEMS);
   double* sc = gpx_static_scratch(h->device);
   GPX_REQUIRE(sc != nullptr, "gemv_static: static scratch of device %d was not initialised", h->device);

@@ -133,6 +133,7 @@ int gpx_dot_launch(hipStream_t s, int n, const double* x, const double* y, doubl
 int gpx_gemv_launch(hipStream_t s, int trans, int n, int m, const double* A, long lda,
                     const double* x, double* y, double* red, size_t red_elems, double alpha = 1.0,
                     double beta = 0.0);   // y = alpha op(A) x + beta y
+bool gpx_gemv_partials_fit(int n, int m, size_t red_elems);   // transposed product: chunks x m <= red_elems?
 int gpx_symmetrize_launch(hipStream_t s, int n, double* A, long lda);
 int gpx_diag_launch(hipStream_t s, int n, const double* A, long lda, double* out);
 int gpx_ep_scale_launch(hipStream_t s, int n, const double* K, long ldk, const double* sv, double* B,

@@ -41,7 +41,13 @@ __device__ __forceinline__ double horner(double p, double r, double c) {
 // underflows gradually through v_ldexp_f64.  The coefficients sit in SGPR pairs (see horner()).
 constexpr int EXP_TAB = 64;
 
+// h is clamped to 800 first (ONE v_min_f64): exp(-800) = 2^-1154 underflows to an exact 0 through ldexp, kf stays
+// within +-2^17 (no int overflow in the conversion -- unscaled features or a large beta on an L-BFGS-B excursion
+// reach h ~ 1e9 easily) and h = +inf gives 0 as exp(-inf) does.  v_min_f64 returns the non-NaN operand, so a NaN
+// coordinate would give 0 here: the Python layer rejects non-finite training inputs (check_X_y) and restores the
+// NaNs of non-finite test points on the host (regression.py / kernels.py: _nan_rows).
 __device__ __forceinline__ double exp_neg_tab(double h, const double* tab) {
+  h = __builtin_fmin(h, 800.0);
   const double kf = rint(h * -9.23324826168936574e+01);            // -64 / ln 2
   double r = fma(kf, -1.0830417275428772e-02, -h);                 // r = -h - kf * ln2/64: hi part (32 trailing zero bits: kf * hi is exact)
   r = fma(kf, -7.420820373486988e-09, r);                          // lo part

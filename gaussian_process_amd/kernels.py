@@ -32,6 +32,24 @@ def _as_2d(X, name):
     return np.ascontiguousarray(X, dtype=np.float64)
 
 
+def _nan_rows(X):
+    """Rows of X with a non-finite coordinate (None if there are none).  The device exp clamps its argument
+    with a v_min_f64, which drops NaNs (csrc/gram.hip: exp_neg_tab); NumPy's exp in kernels.py:37,79 propagates
+    them, so the entries of those rows / columns are put back to NaN on the host."""
+    bad = ~np.isfinite(X).all(axis=1)
+    return bad if bad.any() else None
+
+
+def _restore_nan(arr, bad1, bad2):
+    if arr is None:
+        return arr
+    if bad1 is not None:
+        arr[..., bad1, :] = np.nan
+    if bad2 is not None:
+        arr[..., :, bad2] = np.nan
+    return arr
+
+
 class _StationaryKernel(BaseEstimator):
     """Shared device path of RBF and ARD."""
 
@@ -57,18 +75,20 @@ class _StationaryKernel(BaseEstimator):
         dX2 = dX1 if X2 is X1 else rt.upload_matrix(X2)
         K = rt.matrix(n1, n2)
         ld = K.shape[1]
+        bad1 = _nan_rows(X1)
+        bad2 = bad1 if X2 is X1 else _nan_rows(X2)
         if not want_dtheta:
             _lib.check(lib.gpx_gram(rt.h, kind, ptr(dX1), n1, dX1.shape[1], ptr(dX2), n2, dX2.shape[1],
                                     dim, sigma, beta_p, 0.0, ptr(K), ld, _lib.GPX_FULL), "gpx_gram")
-            return rt.download(K[:n1, :n2]), None, None
+            return _restore_nan(rt.download(K[:n1, :n2]), bad1, bad2), None, None
         nplanes = len(beta_arr)
         dsig = rt.matrix(n1, n2)
         dbeta = rt.torch.empty((nplanes, max(n1, 1), ld), dtype=rt.torch.float64, device=rt.dev)
         _lib.check(lib.gpx_gram_dtheta(rt.h, kind, ptr(dX1), n1, dX1.shape[1], ptr(dX2), n2,
                                        dX2.shape[1], dim, sigma, beta_p, ptr(K), ptr(dsig), ptr(dbeta),
                                        ld, max(n1, 1) * ld), "gpx_gram_dtheta")
-        return (rt.download(K[:n1, :n2]), rt.download(dsig[:n1, :n2]),
-                rt.download(dbeta[:, :n1, :n2]))
+        return (_restore_nan(rt.download(K[:n1, :n2]), bad1, bad2), _restore_nan(rt.download(dsig[:n1, :n2]), bad1, bad2),
+                _restore_nan(rt.download(dbeta[:, :n1, :n2]), bad1, bad2))
 
     def gram_only(self, X1, X2=None):
         """K(X1, X2) as a host array without the derivative planes ``__call__`` also builds and downloads

@@ -153,6 +153,9 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         ``batch`` at a time (device memory n x batch, any m)."""
         X = np.ascontiguousarray(np.asarray(X), dtype=np.float64)
         assert X.ndim == 2 and X.shape[1] == self.dim
+        if not np.isfinite(X).all():
+            # regression.py:38: scipy's solve_triangular (check_finite=True) raises on the NaN column of k*
+            raise ValueError("array must not contain infs or NaNs")
         m = X.shape[0]
         if not full_cov and m > batch:
             parts = [self.predict_with_variance(X[i:i + batch], full_cov=False, batch=batch)

@@ -51,7 +51,11 @@ typedef struct gpx_handle gpx_handle;
 /* ---- life cycle ---------------------------------------------------------------------- */
 int gpx_create(gpx_handle** out, int device);
 int gpx_destroy(gpx_handle* h);
-/* stream: a hipStream_t (torch.cuda.current_stream().cuda_stream); NULL = default stream. */
+/* stream: a hipStream_t (torch.cuda.current_stream().cuda_stream); NULL = default stream.
+ * A handle's scratch (the reduction partials, the split-K workspace of the GEMM, the pinned staging buffer)
+ * serves ONE stream at a time: work given to the handle on two streams must not overlap in time (re-bind only
+ * after the new stream waits for the old one, as the Python runtime's bind_stream() does), or use one handle
+ * per stream. */
 int gpx_set_stream(gpx_handle* h, void* stream);
 int gpx_synchronize(gpx_handle* h);
 const char* gpx_last_error(void);
@@ -147,9 +151,12 @@ int gpx_colsumsq_sub(gpx_handle* h, int n, int m, const double* V, int ldv, doub
 /* gpx_gemv for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc): the same kernels, but the partial sums of the transposed product live in a
  * file-scope 2 MiB device array of the library instead of the handle's hipMalloc'ed scratch.  It has no
- * counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine.  Limits: m <= 262144
- * (2^18) and n <= 2^28, larger shapes return GPX_EINVAL.  All calls on one GPU share that GPU's array:
- * calls that overlap on one GPU (two streams, two threads) race; calls on one stream are ordered. */
+ * counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine.  Limit (transposed
+ * product, trans = 1): the partial sums -- ceil(n / rows) chunks of m doubles, rows = 256 doubled up to 2^20
+ * until they fit -- must fit the 262144 (2^18) doubles of the array, i.e. ceil(n / 2^20) * m <= 2^18; shapes
+ * beyond that return GPX_EINVAL ("exceeds the static scratch").  The plain product (trans = 0) uses no scratch
+ * and has no limit of its own.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two streams, two threads) race; calls on one stream are ordered. */
 int gpx_gemv_static(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,
                     double* y);
 /* out_host[0] = x . y */

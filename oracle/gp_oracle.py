@@ -273,6 +273,18 @@ def ep_lml(state, y):
     return float(t0 + t1 + t2 + t3 + t4 + t5 + t6)
 
 
+def ep_grad(state, dK):
+    """expectation_propagation.py:161-166 for ONE derivative matrix dK (n x n): the pair
+    [b^T dK b / 2, tr(U^T U dK) / 2] with U = L^-1 diag(S), b = nu - U^T U K nu (K jittered, as :163).
+    For ARD the caller passes the planes of kernels.py:80 one at a time (the reference's np.trace over
+    the whole (d, n, n) stack is not a per-dimension gradient)."""
+    L, s, K, nu = state["L"], state["S"], state["K"], state["nu"]
+    U = sla.solve_triangular(L, np.diag(s), lower=True, check_finite=False)
+    UtU = U.T @ U
+    b = nu - UtU @ (K @ nu)
+    return [0.5 * float(b @ dK @ b), 0.5 * float(np.sum(UtU * dK.T))]
+
+
 # --------------------------------------------------------------------------
 # distillation: EP over a two-task Kronecker kernel -- distillation.py:22-63
 # --------------------------------------------------------------------------

@@ -43,6 +43,50 @@ def test_ep_matches_reference(name):
     assert abs(grads["cov__beta"] - float(g["grad_cov_beta"])) < 1e-6 * abs(float(g["grad_cov_beta"]))
 
 
+@pytest.mark.parametrize("kind", ["rbf", "ard"])
+def test_ep_gradient_rbf_and_ard(kind):
+    """Device EP gradient (U = L^-1 S by TRSM, U^T U on the matrix cores, the two trace terms by the fused
+    trace kernel) against the oracle's restatement of expectation_propagation.py:161-166, plane by plane, from
+    the SAME fitted state, with splitted_terms True and False.  ARD: the per-dimension gradient (deliberate
+    deviation, see the method's docstring) -- parity pinned by the oracle only."""
+    from gaussian_process_amd import GaussianProcessExpectationPropagation, RBF, ARD
+    from oracle import gp_oracle as O
+    g = load_golden("g4_ep_moons_n200")
+    X, y = g["Xtr"], g["ytr"]
+    n, d = X.shape
+    beta = np.array([0.7, 1.9]) if kind == "ard" else np.array([1.3])
+    cov = ARD(sigma=1.4, beta=beta) if kind == "ard" else RBF(sigma=1.4, beta=float(beta[0]))
+    ep = GaussianProcessExpectationPropagation(cov)
+    ep.Xtr, ep.ytr, ep.n, ep.dim = X, y, n, d
+    K, dsig, dbeta = O.cov(kind, X, None, 1.4, beta, want_grad=True)
+    ep._ep(K.copy(), shuffle=False)
+    state = dict(L=ep.L, S=ep.S.ravel(), K=K + 1e-8 * np.eye(n), nu=ep.nu_tilde)
+    want_sigma = O.ep_grad(state, dsig)
+    want_beta = [O.ep_grad(state, dbeta)] if kind == "rbf" else [O.ep_grad(state, dbeta[k]) for k in range(d)]
+    split = ep.grad_log_marginal_likelihood(splitted_terms=True)
+    assert list(split) == ["cov__sigma", "cov__beta"]
+    tol = lambda v: 1e-8 * max(1.0, abs(v))
+    for i in range(2):
+        assert abs(split["cov__sigma"][i] - want_sigma[i]) < tol(want_sigma[i])
+    if kind == "rbf":
+        for i in range(2):
+            assert abs(split["cov__beta"][i] - want_beta[0][i]) < tol(want_beta[0][i])
+    else:
+        for i in range(2):
+            assert np.shape(split["cov__beta"][i]) == (d,)
+            for k in range(d):
+                assert abs(split["cov__beta"][i][k] - want_beta[k][i]) < tol(want_beta[k][i])
+    total = ep.grad_log_marginal_likelihood()
+    assert abs(total["cov__sigma"] - sum(want_sigma)) < tol(sum(want_sigma))
+    if kind == "rbf":
+        assert np.ndim(total["cov__beta"]) == 0
+        assert abs(total["cov__beta"] - sum(want_beta[0])) < tol(sum(want_beta[0]))
+    else:
+        assert np.shape(total["cov__beta"]) == (d,)      # what base.py:38-39 flattens into the optimiser's vector
+        for k in range(d):
+            assert abs(total["cov__beta"][k] - sum(want_beta[k])) < tol(sum(want_beta[k]))
+
+
 def test_ep_notebook_fit_score():
     """examples/expectation_propagation.ipynb: fit() with the RNG-driven site order scores 0.92."""
     from gaussian_process_amd import GaussianProcessExpectationPropagation, RBF

@@ -135,6 +135,51 @@ def test_gram_matches_oracle(rt, kind, d, n1, n2):
         assert np.all(np.triu(blk, 1) == 0.0)
 
 
+@pytest.mark.parametrize("kind", ["rbf", "ard"])
+def test_gram_huge_exponent_is_an_exact_zero(rt, kind):
+    """beta * dist^2 ~ 1e9 .. 1e300 (unscaled features, a large beta on an L-BFGS-B excursion): exp underflows to an
+    exact 0 as numpy's does (kernels.py:37,79) -- no NaN, no garbage from an overflowing int conversion."""
+    from gaussian_process_amd import _lib
+    d = 2
+    X = np.array([[0.0, 0.0], [1.0, 0.0], [3e4, 0.0], [0.0, 2e7], [1e150, 0.0], [1.0, 1e-3]])
+    beta = np.array([2.0, 1.0]) if kind == "ard" else np.array([2.0])
+    barr, bp = _lib.host_doubles(beta)
+    dX = up(rt, X)
+    n = X.shape[0]
+    K = rt.matrix(n, n)
+    ok(rt.lib.gpx_gram(rt.h, _lib.GPX_KIND[kind], P(dX), n, dX.shape[1], None, 0, 0, d, 1.5, bp, 0.0, P(K), K.shape[1], 0))
+    got = down(rt, K, n, n)
+    with np.errstate(over="ignore"):
+        Ko, _, _ = O.cov(kind, X, None, 1.5, beta)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got == 0.0, Ko == 0.0)
+    assert relerr(got, Ko) < 1e-13
+    # the fused gradient trace uses the same exp: finite sums with such points in the data
+    alpha = up(rt, np.ones((1, n)))
+    Kinv = up(rt, np.eye(n))
+    out = (C.c_double * (2 + len(beta)))()
+    ok(rt.lib.gpx_grad_trace(rt.h, _lib.GPX_KIND[kind], P(dX), n, dX.shape[1], d, 1.5, bp, P(alpha), P(Kinv),
+                             Kinv.shape[1], None, C.cast(out, C.POINTER(C.c_double))))
+    assert np.isfinite(np.array(list(out))[:2]).all()
+
+
+def test_non_finite_inputs_behave_as_in_the_reference(rt):
+    """NumPy's exp propagates NaN (kernels.py:37,79); the device exp clamps with a min that drops it, so the
+    Python layer puts the NaNs back.  predict raises as scipy's solve_triangular does (regression.py:38)."""
+    from gaussian_process_amd import RBF, ARD, GaussianProcessRegression
+    rng = np.random.default_rng(0)
+    X1, X2 = rng.uniform(-1, 1, (6, 2)), rng.uniform(-1, 1, (5, 2))
+    X2[3, 1] = np.nan
+    for cov in (RBF(1.0, 0.5), ARD(1.0, [0.5, 2.0])):
+        kv = cov(X1, X2)
+        assert np.isnan(kv.K[:, 3]).all() and np.isfinite(np.delete(kv.K, 3, axis=1)).all()
+        assert np.isnan(kv.dtheta["sigma"][:, 3]).all() and np.isnan(kv.dtheta["beta"][..., 3]).all()
+    gp = GaussianProcessRegression(cov=RBF(), sigma=0.1)
+    gp.fit(X1, rng.standard_normal(6))
+    with pytest.raises(ValueError):
+        gp.predict(X2)
+
+
 def test_gram_dtheta_matches_oracle(rt):
     from gaussian_process_amd import RBF, ARD
     rng = np.random.default_rng(5)

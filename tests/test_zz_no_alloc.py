@@ -24,9 +24,22 @@ def _run(rt, n, m, trans, seed):
     y_new = rt.vector(nout, zero=True)
     rc = lib.gpx_gemv(rt.h, trans, n, m, ptr(A), A.shape[1], ptr(x), ptr(y_ref))
     assert rc == 0, rc
+    if trans:
+        # poison the shared array: the same call on a NaN vector leaves NaN in every partial-sum slot this
+        # shape uses; the real call below has to overwrite them all
+        xnan = rt.upload_vector(np.full(n, np.nan))
+        ytmp = rt.vector(nout, zero=True)
+        rc = lib.gpx_gemv_static(rt.h, trans, n, m, ptr(A), A.shape[1], ptr(xnan), ptr(ytmp))
+        assert rc == 0, (rc, lib.gpx_last_error())
+        torch.cuda.synchronize()
+        assert np.isnan(rt.download(ytmp[:nout])).all()
+    # the property the entry point exists for: the call allocates and frees nothing on the device
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(rt.dev)[0]
     rc = lib.gpx_gemv_static(rt.h, trans, n, m, ptr(A), A.shape[1], ptr(x), ptr(y_new))
     assert rc == 0, (rc, lib.gpx_last_error())
     torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(rt.dev)[0] == free0
     a = rt.download(y_ref[:nout])
     b = rt.download(y_new[:nout])
     exact = A_h.T @ x_h if trans else A_h @ x_h
@@ -60,5 +73,13 @@ def test_gemv_static_rejects_sizes_beyond_the_scratch():
     y = rt.vector(2)
     m_big = (1 << 18) + 2
     rc = rt.lib.gpx_gemv_static(rt.h, 1, 2, m_big, ptr(A), m_big, ptr(x), ptr(y))
+    assert rc == -1
+    assert b"exceeds the static scratch" in rt.lib.gpx_last_error()
+    # inside the old documented box (m <= 2^18, n <= 2^28) but two chunks of 2^18 partials: rejected up front with
+    # GPX_EINVAL, not GPX_ENOMEM from inside the launch (nothing is read: the check comes before any access)
+    rc = rt.lib.gpx_gemv_static(rt.h, 1, (1 << 20) + 1, 1 << 18, ptr(A), 1 << 18, ptr(x), ptr(y))
+    assert rc == -1
+    assert b"exceeds the static scratch" in rt.lib.gpx_last_error()
+    rc = rt.lib.gpx_gemv_static(rt.h, 1, (1 << 21) + 5, (1 << 17) + 2, ptr(A), (1 << 17) + 2, ptr(x), ptr(y))
     assert rc == -1
     assert b"exceeds the static scratch" in rt.lib.gpx_last_error()
