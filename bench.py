@@ -264,6 +264,158 @@ def public_api_leg(X, y, Xs, beta, torch):
     return out
 
 
+def other_configs_leg(torch):
+    """The BASELINE configs other than the headline, a few seconds of GPU time, so that the driver's record
+    carries them too: C2 -- 2-D ARD regression with the LML optimisation of base.py:21-58 scaled to
+    n = 4096: evaluations x time; C3 -- synthetic ARD n = 16384, d = 8: fused LML + gradient, prediction, potrf
+    alone; C5 -- EP classification make_moons n = 8192 (expectation_propagation.py:16-108): fit, sweeps, time per
+    sweep split into the device site loop and the recompute; and the potrf ladder at the mid sizes."""
+    from gaussian_process_amd import ARD, RBF, GaussianProcessRegression, GaussianProcessExpectationPropagation, _lib
+    from gaussian_process_amd.datasets import synthetic_ard
+    from gaussian_process_amd.device import runtime
+    out = {}
+    sync = torch.cuda.synchronize
+
+    class Counting(GaussianProcessRegression):
+        evals = 0
+
+        def _evaluate(self, need_grad):
+            st = getattr(self, "_state", None)
+            hit = st is not None and st["key"] == self._theta_key() and (st["grad"] is not None or not need_grad)
+            if not hit:
+                Counting.evals += 1
+            return super()._evaluate(need_grad)
+
+    # ---- C2
+    n2 = 4096
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-3, 3, (n2, 2))
+    y = np.sin(X[:, 0]) * np.cos(2.0 * X[:, 1]) + 0.1 * rng.standard_normal(n2)
+    Xs = rng.uniform(-3, 3, (1000, 2))
+    gp = Counting(cov=ARD(beta=np.array([1.0, 1.0])))
+    gp.fit(X, y)
+    gp.log_marginal_likelihood()
+    gp.grad_log_marginal_likelihood()
+    gp._state = None
+    sync()
+    t0 = time.perf_counter()
+    gp.grad_log_marginal_likelihood()
+    gp.log_marginal_likelihood()
+    sync()
+    t_eval = time.perf_counter() - t0
+    Counting.evals = 0
+    t0 = time.perf_counter()
+    gp.fit(X, y, empirical_bayes=True)
+    sync()
+    t_eb = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gp.predict(Xs)
+    sync()
+    t_pred = time.perf_counter() - t0
+    out["C2_ard2d_n4096_empirical_bayes"] = {
+        "evaluations": Counting.evals, "empirical_bayes_s": round(t_eb, 4),
+        "ms_per_evaluation": round(1e3 * t_eb / max(Counting.evals, 1), 3),
+        "one_fused_evaluation_ms": round(1e3 * t_eval, 3), "predict_m1000_s": round(t_pred, 4),
+        "beta": [float(b) for b in np.asarray(gp.cov.beta)], "lml": float(gp.log_marginal_likelihood())}
+    del gp
+    # ---- C3
+    n3, m3 = 16384, 4096
+    X, y, Xs, beta = synthetic_ard(n3, m=m3, d=8, seed=0, noise=0.1)
+    gp = GaussianProcessRegression(ARD(sigma=1.0, beta=beta), sigma=0.1)
+    gp.fit(X, y)
+    for rep in range(2):
+        gp._state = None
+        sync()
+        t0 = time.perf_counter()
+        lml = gp.log_marginal_likelihood()
+        gp.grad_log_marginal_likelihood()
+        sync()
+        t1 = time.perf_counter()
+        gp.predict_with_variance(Xs)
+        sync()
+        t2 = time.perf_counter()
+    out["C3_ard8_n16384"] = {"lml_and_grad_s": round(t1 - t0, 4), "lml_and_grad_tflops_on_n3": round(n3 ** 3 / (t1 - t0) / 1e12, 2),
+                             "predict_with_variance_m4096_s": round(t2 - t1, 4), "lml": float(lml)}
+    del gp
+    torch.cuda.empty_cache()
+    # ---- potrf ladder (C ABI, HIP events)
+    rt = runtime(0)
+    rt.bind_stream()
+    ladder = {}
+    for n in (2048, 4096, 8192, 16384):
+        G = torch.rand((n, 64), dtype=torch.float64, device=rt.dev) - 0.5
+        S = G @ G.T / 64 + torch.eye(n, dtype=torch.float64, device=rt.dev)
+        W = torch.empty_like(S)
+        dinv = rt.dinv(n)
+        info = torch.zeros(4, dtype=torch.int32, device=rt.dev)
+        best = 1e9
+        for rep in range(4):
+            W.copy_(S)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(rt.lib.gpx_potrf_async(rt.h, n, P(W), n, P(dinv), P(info), 0), "potrf")
+            e1.record()
+            sync()
+            best = min(best, e0.elapsed_time(e1))
+        ladder["n%d" % n] = {"ms": round(best, 3), "tflops": round(n ** 3 / 3 / best / 1e9, 2)}
+        del G, S, W
+    out["potrf_ladder"] = ladder
+    torch.cuda.empty_cache()
+    # ---- C5
+    from sklearn.datasets import make_moons
+    n5 = 8192
+    X, y = make_moons(n5, noise=0.1, random_state=0)
+    y = 2.0 * y - 1.0
+    tim = {"sweep": [], "recompute": []}
+    for rep in range(2):
+        np.random.seed(0)
+        ep = GaussianProcessExpectationPropagation(RBF())
+        if rep == 1:       # second fit instrumented: synchronise around the sweep and the recompute
+            def timed(name, f):
+                def g(*a):
+                    sync(); t0 = time.perf_counter(); r = f(*a); sync()
+                    tim[name].append(time.perf_counter() - t0)
+                    return r
+                return g
+            ep._sweep, ep._recompute = timed("sweep", ep._sweep), timed("recompute", ep._recompute)
+        sync()
+        t0 = time.perf_counter()
+        ep.fit(X, y)
+        sync()
+        t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    acc = float(np.mean(ep.predict(X[:2000]) == y[:2000]))
+    sync()
+    t_pred = time.perf_counter() - t0
+    out["C5_ep_moons_n8192"] = {"fit_s": round(t_fit, 4), "sweeps": len(tim["sweep"]),
+                                "site_sweep_s": round(float(np.mean(tim["sweep"])), 4),
+                                "recompute_s": round(float(np.mean(tim["recompute"][1:])), 4),
+                                "us_per_site": round(1e6 * float(np.mean(tim["sweep"])) / n5, 2),
+                                "predict_2000_s": round(t_pred, 4), "train_accuracy_2000": acc,
+                                "lml": float(ep.log_marginal_likelihood())}
+    del ep
+    torch.cuda.empty_cache()
+    return out
+
+
+def extrapolate_cpu(base, n_cpu, m_cpu, n, m):
+    """cpu_baseline stages measured at n_cpu scaled to the headline size by each stage's leading term (SURVEY 8d:
+    'else extrapolate by n^3 and label it'): Cholesky and gradient n^3, Gram and the two solves n^2, prediction
+    n^2 m (its TRSM).  An EXTRAPOLATION, not a measurement: at n = 65536 the restatement needs ~105 GB for Ky,
+    its inverse and the gradient's temporaries."""
+    st = base.get("stages_s")
+    if not st:
+        return None
+    r = n / float(n_cpu)
+    pred_key = [k for k in st if k.startswith("predict")][0]
+    parts = {"gram": st["gram"] * r ** 2, "cholesky": st["cholesky"] * r ** 3,
+             "solves_lml_alpha": st["solves_lml_alpha"] * r ** 2,
+             "predict_m%d" % m: st[pred_key] * r ** 2 * (m / float(m_cpu)),
+             "gradient_potri_traces": st["gradient_potri_traces"] * r ** 3}
+    return {"label": "extrapolated from the n=%d stages (not measured)" % n_cpu,
+            "stages_s": {k: round(v, 1) for k, v in parts.items()}, "fit_predict_s": round(sum(parts.values()), 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +430,7 @@ def main():
     ap.add_argument("--block", type=int, default=0,
                     help="block-column width of the multi-GPU Cholesky (0: 2048 on 1-2 ranks, 1024 on 4, 512 on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-only", action="store_true",
                     help="run only the CPU baseline (--cpu-n, --cpu-m) in this process and print it; no GPU is touched")
     args = ap.parse_args()
@@ -368,8 +521,15 @@ def main():
                 del bufs[k]                       # the estimator allocates its own resident buffers
         torch.cuda.empty_cache()
         out["public_api"] = public_api_leg(X, y, Xs, beta, torch)
+    if not args.no_other_configs:
+        bufs.clear()
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs_leg(torch)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_m)
+        ex = extrapolate_cpu(out["cpu_baseline"], args.cpu_n, args.cpu_m, n, m)
+        out["cpu_baseline"]["extrapolated_n%d_s" % n] = ex["fit_predict_s"] if ex else None
+        out["cpu_baseline"]["extrapolated_n%d" % n] = ex
     print(json.dumps(out))
 
 

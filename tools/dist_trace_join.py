@@ -1,6 +1,8 @@
 """Join GPX_GEMM_LOG shapes with the kernel trace of the distributed step (tools/dist_trace.sh).  The engine
 launches on two streams, so the join is by dispatch id (host launch order), not by start time."""
-import csv, sys, collections
+import csv, sys, collections, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from trace_common import parse_shape, merge_parts, PEAK_TF
 d = sys.argv[1]
 shapes, phase_of, phase, nstart = [], [], "warmup", 0
 for l in open(d + "/gemmlog.txt"):
@@ -19,26 +21,26 @@ gem = [r for r in rows if "gemm_f64_kernel" in r["Kernel_Name"]]
 print("gemm launches in trace %d, in log %d" % (len(gem), len(shapes)))
 cls = collections.OrderedDict()
 big = collections.OrderedDict()
-for r, s, ph in zip(gem, shapes, phase_of):
+assert len(gem) == len(shapes), "trace and log disagree: the join would be wrong"
+dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+# main / tail / split-K parts of one launch merged: time added, flops once (trace_common.py)
+logical = merge_parts([(parse_shape(s), dur(r), ph) for r, s, ph in zip(gem, shapes, phase_of)])
+for sh, t, fl, nk, ph in logical:
     if not ph.startswith("timed-"):
         continue
-    M, N, K = int(s[1]), int(s[2]), int(s[3])
-    lower = int(s[4].split("=")[1]); atri = int(s[5].split("=")[1]); btri = int(s[6].split("=")[1])
-    fl = 2.0 * M * N * K * (0.5 if lower else 1.0) * (0.5 if (atri or btri) else 1.0)
-    if len(s) > 9 and s[9] != "part=main":
-        fl = 0.0          # tail / split-K parts of a launch logged with the launch's full shape: time only
-    t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    M, N, K = sh["M"], sh["N"], sh["K"]
     kc = "K<=128" if K <= 128 else "K<=512" if K <= 512 else "K<=2048" if K <= 2048 else "K<=8192" if K <= 8192 else "K>8192"
     nc = "N<=128" if N <= 128 else "N<=512" if N <= 512 else "N<=2048" if N <= 2048 else "N>2048"
-    key = "%-16s %-8s %-8s tri=%d%d low=%d" % (ph[6:], kc, nc, atri, btri, lower)
+    key = "%-16s %-8s %-8s tri=%d%d low=%d" % (ph[6:], kc, nc, sh["atri"], sh["btri"], sh["lower"])
     c = cls.setdefault(key, [0, 0.0, 0.0])
     c[0] += 1; c[1] += t; c[2] += fl
-    if ph == "timed-potrf" and K >= 2048 and fl > 0:
+    if ph == "timed-potrf" and K >= 2048:
         big.setdefault((M, N, K), []).append(t)
 tot = collections.defaultdict(lambda: [0.0, 0.0])
 for k in sorted(cls):
     c = cls[k]
     print("%s launches %5d  time %8.2f ms  flops %8.3f T  rate %6.2f TF" % (k, c[0], c[1] * 1e3, c[2] / 1e12, c[2] / c[1] / 1e12))
+    assert c[2] / c[1] / 1e12 <= PEAK_TF, "a class above the fp64 MFMA peak: flop model or join wrong"
     ph = k.split()[0]
     tot[ph][0] += c[1]; tot[ph][1] += c[2]
 for ph, (t, f) in tot.items():
@@ -52,7 +54,11 @@ for r in rows:
 print("other kernels (warm-up + timed step):")
 for k, v in sorted(other.items(), key=lambda kv: -kv[1][1])[:12]:
     print("  %-52s %6d %9.2f ms" % (k, v[0], v[1]))
-print("potrf launches with K >= 2048 (main part), every 8th:")
+lk = [r for r in rows if "leaf_blocked_kernel" in r["Kernel_Name"] or "potrf_chain" in r["Kernel_Name"]]
+if lk:
+    ts = sorted(dur(r) for r in lk)
+    print("leaf / chain kernels: %d, average %.1f us, median %.1f us, max %.1f us" % (len(ts), 1e6 * sum(ts) / len(ts), 1e6 * ts[len(ts) // 2], 1e6 * ts[-1]))
+print("potrf launches with K >= 2048 (parts merged), every 8th:")
 for i, ((M, N, K), ts) in enumerate(big.items()):
     if i % 8 == 0:
         print("  %6d %5d %6d x%d  %9.1f us  %6.1f TF" % (M, N, K, len(ts), 1e6 * sum(ts) / len(ts), 2.0 * M * N * K / (sum(ts) / len(ts)) / 1e12))
