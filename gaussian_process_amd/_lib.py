@@ -38,6 +38,7 @@ SIGNATURES = {
     "gpx_lauum_upper": (_i, [C.c_void_p, _i, _dp, _i, _dp]),
     "gpx_syrk_sub": (_i, [C.c_void_p, _i, _i, _dp, _i, _dp, _i, _d, _i]),
     "gpx_gemm": (_i, [C.c_void_p, _i, _i, _i, _i, _i, _d, _dp, _i, _dp, _i, _d, _dp, _i]),
+    "gpx_gemm_colblocks": (_i, [C.c_void_p, _i, _i, _i, _d, _dp, _i, _dp, _i, _d, _dp, _i, _i, _dp, _dp]),
     "gpx_trmv": (_i, [C.c_void_p, _i, _i, _dp, _i, _dp, _dp]),
     "gpx_trmm": (_i, [C.c_void_p, _i, _i, _i, _dp, _i, _dp, _i, _dp, _i]),
     "gpx_gemv": (_i, [C.c_void_p, _i, _i, _i, _dp, _i, _dp, _dp]),

@@ -287,6 +287,19 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
     pace_live = (unsigned)__popcll(__ballot(alive));   // (every wave computes it; thread 0 uses it)
     pace = g.sync_cnt + st;
   }
+  if (g.cb_off != nullptr) {   // column-block output: this tile's slab; tiles above the slab's first row do not exist
+    const int c = (bj * BN) / g.cb_nb;
+    // rows above the slab's first row do not exist; inside the slab's first cb_nb rows (its DIAGONAL tile) the
+    // tiles strictly above that tile's diagonal are never read by the factorisation and are skipped as well, so
+    // the launch does exactly the lower trapezoid's flops (full squares cost 4.7 % more at cb_nb = 2048)
+    // (bit 0 of the table entry flags a slab whose first tile IS the diagonal tile: on a P x Q grid the slab of a
+    // column this process row does not own the diagonal tile of starts with a full tile below the diagonal)
+    const int r0e = g.cb_row0[c];
+    const int rel_last = g.cb_rowbase + bi * BM + BM - 1 - (r0e & ~1);   // last row of the tile, slab-relative
+    if (rel_last < ((r0e & 1) ? bj * BN - c * g.cb_nb : 0)) return;   // (workgroup-uniform, before any barrier)
+    g.D += g.cb_off[c] + (long)g.cb_rowbase * g.cb_nb - (long)c * g.cb_nb;
+    g.Cin = g.D;
+  }
   if (g.c_upper) {   // mirror image of the lower enumeration (symmetric product): tile (bj, bi) on or above the diagonal
     const int tmp = bi;
     bi = bj;
@@ -655,7 +668,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
   static const long pace_on = env_long("GPX_GEMM_PACE", 0);   // development switch
   static const long pace_kt = env_long("GPX_GEMM_PACE_KT", SYNC_KT);   // development override (a power of two)
   GemmDesc gp = g;
-  if (pace_on && !batched && nsuper != 0 && TM * TN >= 16 && t_ws != nullptr && !g.a_tri && !g.b_tri && !g.inplace &&
+  if (pace_on && !batched && nsuper != 0 && TM * TN >= 16 && t_ws != nullptr && !g.a_tri && !g.b_tri && !g.inplace && !g.cb_off &&
       g.K >= 2 * pace_kt * BK && (size_t)nsuper * sizeof(unsigned) <= t_ws_elems * sizeof(double)) {
     gp.sync_cnt = reinterpret_cast<unsigned*>(t_ws);
     gp.sync_kt = (int)pace_kt;
@@ -703,7 +716,7 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
     const unsigned main_tiles = (unsigned)(ntiles - rem);
     launch(dim3(main_tiles), 0, 0);
     int split = 0;
-    if (splitk_on && t_ws != nullptr && rem <= 128 && g.K >= 1024 && !g.a_tri && !g.b_tri && !g.inplace && !g.c_upper) {
+    if (splitk_on && t_ws != nullptr && rem <= 128 && g.K >= 1024 && !g.a_tri && !g.b_tri && !g.inplace && !g.c_upper && !g.cb_off) {
       split = (int)(256 / rem);
       while (split > 1 && g.K / split < 128) --split;
       if ((size_t)rem * split * (BM * BN) > t_ws_elems) split = (int)(t_ws_elems / ((size_t)rem * BM * BN));
@@ -759,7 +772,11 @@ int gpx_gemm_launch(hipStream_t s, const GemmDesc& g) {
   GPX_REQUIRE((g.lda & 1) == 0 && (g.ldb & 1) == 0, "gemm: leading dimensions must be even");
   GPX_REQUIRE(g.lda >= (g.a_lay == GPX_LAY_KC ? g.K : g.M), "gemm: lda too small");
   GPX_REQUIRE(g.ldb >= (g.b_lay == GPX_LAY_KC ? g.K : g.N), "gemm: ldb too small");
-  GPX_REQUIRE(g.ldd >= g.N, "gemm: ldd too small");
+  GPX_REQUIRE(g.cb_off != nullptr || g.ldd >= g.N, "gemm: ldd too small");
+  GPX_REQUIRE(g.cb_off == nullptr || (g.cb_row0 != nullptr && g.cb_nb >= 128 && g.cb_nb % 128 == 0 && g.cb_rowbase % 128 == 0 &&
+                                       g.ldd == g.cb_nb && g.ldcin == g.cb_nb && g.Cin == g.D && !g.c_lower && !g.inplace &&
+                                       g.batch == 1),
+              "gemm: column-block output needs tables, a block width / row base that are multiples of 128, ldd = the block width and Cin = D");
   GPX_REQUIRE(g.lda < (1L << 21) && g.ldb < (1L << 21), "gemm: leading dimension >= 2^21 (32-bit lane offsets)");
   // Very long K: the 64 workgroups of a super-tile run without any mutual synchronisation and drift
   // apart in k until the panels they share no longer meet in the XCD's 4 MiB L2 (measured, M = N = K =

@@ -514,6 +514,26 @@ int gpx_gemm(gpx_handle* h, int transa, int transb, int M, int N, int K, double 
   return gpx_gemm_launch(h->stream, g);
 }
 
+int gpx_gemm_colblocks(gpx_handle* h, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                       int ldb, double beta, double* D, int nb, int row_base, const long long* blk_off,
+                       const int* blk_row0) {
+  GPX_REQUIRE(h != nullptr, "null handle");
+  if (M <= 0 || N <= 0) return 0;
+  GPX_REQUIRE(A && B && D && blk_off && blk_row0, "gemm_colblocks: null argument");
+  GPX_REQUIRE(nb >= NB && nb % NB == 0 && row_base >= 0 && row_base % NB == 0,
+              "gemm_colblocks: block width %d and row base %d must be multiples of %d", nb, row_base, NB);
+  GPX_REQUIRE(gpx_aligned16(D), "gemm_colblocks: D must be 16-byte aligned");
+  DeviceGuard dg(h);
+  // D_c -= / += A B^T per column block c: A stored M x K, B stored N x K (both k-contiguous)
+  GemmDesc g = mk(A, lda, GPX_LAY_KC, B, ldb, GPX_LAY_KC, D, nb, D, nb, M, N, K, alpha, beta);
+  if (beta == 0.0) g.beta = 0.0;
+  g.cb_off = blk_off;
+  g.cb_row0 = blk_row0;
+  g.cb_nb = nb;
+  g.cb_rowbase = row_base;
+  return gpx_gemm_launch(h->stream, g);
+}
+
 int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,
              double* y) {
   GPX_REQUIRE(h != nullptr && A && x && y, "gemv: null argument");

@@ -81,6 +81,14 @@ struct GemmDesc {
   // size are independent, and at the small sizes a launch per block is launch-latency bound.
   int batch = 1;
   long stride_a = 0, stride_b = 0, stride_d = 0;   // (Cin, when given, moves with D)
+  // Column-block output (the grouped trailing update of the sharded Cholesky, gpx_gemm_colblocks): the N columns
+  // are cb_nb-wide blocks, block c of which lives in its own slab of leading dimension cb_nb -- element (row, col)
+  // at D[cb_off[c] + (cb_rowbase + row) * cb_nb + col - c * cb_nb] -- and exists only from row cb_row0[c] -
+  // cb_rowbase on (tiles above are skipped).  cb_off / cb_row0: DEVICE arrays; Cin == D; cb_nb, cb_rowbase and
+  // every cb_row0[c] multiples of 128.
+  const long long* cb_off = nullptr;
+  const int* cb_row0 = nullptr;
+  int cb_nb = 0, cb_rowbase = 0;
 };
 
 // Workspace of the split-K tail for the calling thread's current handle (set by the C ABI entry points,

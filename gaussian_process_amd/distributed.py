@@ -32,6 +32,7 @@ prediction m test points, the LML gradient slabs of identity columns (Ky^-1 by t
 whole) contracted on the fly by ``gpx_grad_trace_slab``; scalars are all-reduced.
 """
 import ctypes as C
+import os
 from contextlib import contextmanager
 
 import numpy as np
@@ -88,6 +89,13 @@ class GpuOps:
     def gemm(self, ta, tb, M, N, K, alpha, A, B, beta, Cm):
         _lib.check(self.lib.gpx_gemm(self.h, ta, tb, M, N, K, float(alpha), self._p(A), A.stride(0), self._p(B),
                                      B.stride(0), float(beta), self._p(Cm), Cm.stride(0)), "gpx_gemm")
+
+    def gemm_colblocks(self, M, N, K, alpha, A, B, beta, store, nb, row_base, blk_off, blk_row0):
+        """store[slab of column block c] = alpha * A B_c^T + beta * (same), every nb-wide column block c of the N
+        columns in ONE launch (gpx_gemm_colblocks; the tables are device tensors, see allocate())."""
+        _lib.check(self.lib.gpx_gemm_colblocks(self.h, M, N, K, float(alpha), self._p(A), A.stride(0), self._p(B),
+                                               B.stride(0), float(beta), self._p(store), nb, int(row_base),
+                                               self._p(blk_off), self._p(blk_row0)), "gpx_gemm_colblocks")
 
     def trsm_left(self, trans, L, dinv, B):
         _lib.check(self.lib.gpx_trsm(self.h, trans, L.shape[0], B.shape[1], self._p(L), L.stride(0),
@@ -198,6 +206,10 @@ class DistributedGP:
         self.grad_block = grad_block or 4096
         if many_rhs:
             self.MANY_RHS = many_rhs
+        # development switch: one launch per tile column (round 2) instead of grouped trailing updates, for A/B runs
+        self.group_updates = os.environ.get("GPX_DIST_GROUP", "1") != "0"
+        # development switch: the round-2 placement of the diagonal-tile potrf (side stream) for A/B runs
+        self.side_potrf = os.environ.get("GPX_DIST_SIDE_POTRF", "0") == "1" and hasattr(ops, "side_begin")
         # which communicators carry traffic: a dimension of extent 1 needs none.  force_collectives
         # issues them anyway (groups of one rank): the world-size-1 rehearsal of the RCCL branch.
         self.rc = self.Q > 1 or force_collectives          # row sub-communicator (Q ranks)
@@ -332,6 +344,19 @@ class DistributedGP:
             cnt = self.slab_tiles[J] * nb * nb
             self.slabs[J] = self.store[off: off + cnt].view(self.slab_tiles[J] * nb, nb)
             off += cnt
+        # column-block tables of the grouped trailing update (gpx_gemm_colblocks), by LOCAL tile column: element
+        # (local row r, column j) of tile column J lives at store[cb_off + r * nb + j] for r >= cb_row0
+        offs, row0s, off = [], [], 0
+        for J in g.local_cols(q):
+            base = g.lrow(g.first_at_or_after(J, p, self.P))
+            live = self.slab_rows[J] > 0
+            offs.append(off - base * nb if live else 0)
+            # bit 0: the slab's first tile is the diagonal tile (this process row owns it) -- the launch skips the
+            # 128-tiles strictly above its diagonal.  No rows: every tile of the block is skipped.
+            row0s.append((base | (1 if J % self.P == p else 0)) if live else (max(nlr, 1) + 1) * nb)
+            off += self.slab_tiles[J] * nb * nb
+        self.cb_off = t.tensor(offs or [0], dtype=t.int64).to(self.store.device)
+        self.cb_row0 = t.tensor(row0s or [0], dtype=t.int32).to(self.store.device)
         dper = (nb // 128) * 128 * 128
         diag = g.diag_tiles(p, q)
         self.dinv_store = ops.empty(max(len(diag) * dper, 2))
@@ -416,6 +441,45 @@ class DistributedGP:
         if commit:
             self._applied[J] = upto
 
+    def _apply_many(self, cols, upto):
+        """Bring the tile columns `cols` (ascending) up to panel `upto`.  Runs of consecutive local columns with
+        the same pending range share their left operand (the rows of RB below the first column's diagonal tile)
+        and go out as ONE launch with N = (columns) * nb (gpx_gemm_colblocks: every column block lands in its
+        own slab, the tiles above a slab's diagonal tile are skipped) instead of one skinny N = nb product per
+        column -- at nb = 512 those ran at 56-58 TFLOP/s where a wide launch reaches 68-70."""
+        g, nb, G = self.grid, self.nb, self.G
+        grouped = self.group_updates and hasattr(self.ops, "gemm_colblocks")
+        i = 0
+        while i < len(cols):
+            J0 = cols[i]
+            j = i + 1
+            while (grouped and j < len(cols) and cols[j] == cols[j - 1] + self.Q
+                   and self._applied[cols[j]] == self._applied[J0]):
+                j += 1
+            members = cols[i:j]
+            i = j
+            run = [J for J in members if self.slab_rows[J] > 0]
+            if len(run) < 2 or self._applied[J0] >= upto:
+                for J in members:
+                    self._apply(J, upto)
+                continue
+            Ja = run[0]
+            base = g.lrow(g.first_at_or_after(Ja, self.p, self.P))
+            M = self.slab_rows[Ja]
+            N = sum(g.tile_h(J) for J in run)
+            lc0 = Ja // self.Q
+            a = self._applied[Ja]
+            while a < upto:
+                s0 = a % G
+                cnt = min(upto - a, G - s0)
+                self.ops.gemm_colblocks(M, N, cnt * nb, -1.0, self.RB[base: base + M, s0 * nb:(s0 + cnt) * nb],
+                                        self.CB[g.lcol(Ja): g.lcol(Ja) + N, s0 * nb:(s0 + cnt) * nb], 1.0,
+                                        self.store, nb, base, self.cb_off[lc0:], self.cb_row0[lc0:])
+                self.grouped_launches += 1
+                a += cnt
+            for J in members:
+                self._applied[J] = upto
+
     def _post_panel(self, k):
         """Everything that produces panel k and starts it on its way: (column owners) bring tile
         column k up to date, (diagonal owner) factor the diagonal tile and broadcast it down the
@@ -429,24 +493,36 @@ class DistributedGP:
         if q == qk:
             slab, rows = self.slabs[k], self.slab_rows[k]
             mine = p == pk
+            h_diag, dst = None, None
             if mine:
-                # diagonal tile first; its potrf runs on the side stream while the rows below are updated
+                # The diagonal tile first, on the compute stream itself, AHEAD of the update of the rows below it:
+                # the tile's potrf is the factorisation's critical chain (every rank of the column waits for it),
+                # and its 128 x 128 leaves need a whole CU's LDS each.  (Round 2 ran it on a side stream beside
+                # the update of the rows below; with every CU holding two 64-KiB GEMM workgroups a leaf waited
+                # for a CU to drain -- 239 us per leaf on average against 30 us alone, 9 % of the whole potrf.)
                 self._apply(k, k, 0, wk, commit=False)
-                ops.side_begin()
-                ops.potrf_async(slab[:wk, :wk], self.dinv[k], self.info, k * nb)
-                token = ops.side_end()
-                self._apply(k, k, wk, rows)
-                ops.side_join(token)
-            else:
-                self._apply(k, k)
+                if self.side_potrf:
+                    ops.side_begin()
+                    ops.potrf_async(slab[:wk, :wk], self.dinv[k], self.info, k * nb)
+                    token = ops.side_end()
+                    self._apply(k, k, wk, rows)
+                    ops.side_join(token)
+                else:
+                    ops.potrf_async(slab[:wk, :wk], self.dinv[k], self.info, k * nb)
+            if has_panel and self.cc:
+                # the broadcast down the process column leaves as soon as the tile is factored; the update of
+                # the rows below (next) runs under it
+                dst = self.dstg[k % 2]
+                if mine:
+                    dst[: nb * nb].view(nb, nb).copy_(slab[:nb])
+                    dst[nb * nb:].copy_(self.dinv[k])
+                h_diag = self._bcast(dst, self._grank(pk, qk), self.col_group, async_op=True)
+            if not (mine and self.side_potrf):
+                self._apply(k, k, wk if mine else 0, rows)
             if has_panel:
                 Lkk, dk = (slab[:nb], self.dinv[k]) if mine else (None, None)
-                if self.cc:
-                    dst = self.dstg[k % 2]
-                    if mine:
-                        dst[: nb * nb].view(nb, nb).copy_(slab[:nb])
-                        dst[nb * nb:].copy_(self.dinv[k])
-                    self._bcast(dst, self._grank(pk, qk), self.col_group, async_op=True).wait()
+                if h_diag is not None:
+                    h_diag.wait()
                     if not mine:
                         Lkk, dk = dst[: nb * nb].view(nb, nb), dst[nb * nb:]
                 below = slab[nb:rows] if mine else slab[:rows]
@@ -520,6 +596,7 @@ class DistributedGP:
         self.info.zero_()
         self._winv = {}                      # tile inverses belong to the previous factor
         self._applied = {J: 0 for J in self.slabs}
+        self.grouped_launches = 0            # diagnostics: trailing updates issued as grouped launches
         handles = self._post_panel(0)
         for k in range(T - 1):
             self._file_panel(k, handles)
@@ -529,10 +606,12 @@ class DistributedGP:
             # now: its other updates would sit in the stream ahead of the chain it is about to run, and
             # lose nothing by waiting one step (they come back with a longer K).
             chain_next = k + 2 < T and (k + 2) % self.Q == self.q
+            due = []
             for J in g.local_cols(self.q, k + 2):
                 pending = k + 1 - self._applied[J]
                 if J == k + 2 or pending >= G - 1 or (pending >= self.g_upd and not chain_next):
-                    self._apply(J, k + 1)
+                    due.append(J)
+            self._apply_many(due, k + 1)
         # LAPACK info: smallest failing leading minor over all ranks (0 = success)
         big = 2 ** 30
         loc = int(self.info[0].item())

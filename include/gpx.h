@@ -123,6 +123,22 @@ int gpx_syrk_sub(gpx_handle* h, int n, int m, const double* V, int ldv, double* 
  * transa/transb: 0 = stored as op, 1 = stored transposed. */
 int gpx_gemm(gpx_handle* h, int transa, int transb, int M, int N, int K, double alpha,
              const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc);
+/* Grouped trailing update of the sharded (2-D block-cyclic) Cholesky -- the arithmetic of the dsyrk / dgemm
+ * inside scipy.linalg.cholesky (regression.py:36,49) for SEVERAL tile columns in one launch:
+ *   D_c <- alpha * A B_c^T + beta * D_c   for every nb-wide column block c of the N columns,
+ * A stored M x K (lda), B stored N x K (ldb), both k-contiguous.  Column block c is its own slab of leading
+ * dimension nb: element (row, col) of the product lives at D[blk_off[c] + (row_base + row) * nb + col - c * nb]
+ * and exists only for row_base + row >= blk_row0[c] (a slab starts at its diagonal tile; tiles above are
+ * skipped).  Bit 0 of blk_row0[c] set: the slab's first nb rows are the column's DIAGONAL tile, and the 128 x 128
+ * tiles strictly above that tile's diagonal, which the factorisation never reads, are skipped as well (the launch
+ * then does the lower trapezoid's flops; on a P x Q grid a process row that does not own a column's diagonal tile
+ * leaves the bit clear).  blk_off (ceil(N / nb) 64-bit element offsets, may be negative) and blk_row0 are DEVICE arrays owned
+ * by the caller, who guarantees that every addressed element lies inside D's allocation; nb, row_base and every
+ * blk_row0[c] & ~1 must be multiples of 128.  One launch instead of one skinny N = nb product per tile column: the A
+ * panel is shared by all column blocks through the L2. */
+int gpx_gemm_colblocks(gpx_handle* h, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                       int ldb, double beta, double* D, int nb, int row_base, const long long* blk_off,
+                       const int* blk_row0);
 /* y = W x (trans = 0) or y = W^T x (trans = 1) for a lower-triangular n x n matrix W (only W[i][j], j <= i, is
  * read; what lies above the diagonal may be anything); y must not alias x.  With W = L^-1 from gpx_trtri these
  * are a = L^-1 y and alpha = L^-T a of regression.py:50,61 as two streaming passes without a dependent chain:

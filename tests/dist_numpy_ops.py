@@ -73,6 +73,26 @@ class NumpyOps:
         c = Cm.numpy()
         c[:M, :N] = alpha * (opa @ opb) + (beta * c[:M, :N] if beta != 0.0 else 0.0)
 
+    def gemm_colblocks(self, M, N, K, alpha, A, B, beta, store, nb, row_base, blk_off, blk_row0):
+        """Restatement of gpx_gemm_colblocks: column block c of the product goes to its own slab inside `store`,
+        rows from blk_row0[c] on (128-row tiles that start above it are skipped)."""
+        a, b, st = A.numpy()[:M, :K], B.numpy()[:N, :K], store.numpy()
+        off, row0 = blk_off.numpy(), blk_row0.numpy()
+        for c in range((N + nb - 1) // nb):
+            w = min(nb, N - c * nb)
+            diag_first = bool(int(row0[c]) & 1)                 # the slab starts with the column's diagonal tile
+            r0c = int(row0[c]) & ~1
+            r_first = max(0, r0c - row_base)                    # first live row of the launch for this block
+            if r_first >= M:
+                continue
+            prod = a[r_first:] @ b[c * nb: c * nb + w].T
+            for i in range(r_first, M):
+                o = int(off[c]) + (row_base + i) * nb
+                # inside the slab's diagonal tile the 128-tiles strictly above the diagonal are skipped
+                rel = row_base + i - r0c
+                w_live = min(w, (rel // NB + 1) * NB) if (diag_first and rel < nb) else w
+                st[o: o + w_live] = alpha * prod[i - r_first][:w_live] + (beta * st[o: o + w_live] if beta != 0.0 else 0.0)
+
     def trsm_left(self, trans, L, dinv, B):
         l = np.tril(L.numpy())
         b = B.numpy()

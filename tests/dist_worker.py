@@ -110,7 +110,7 @@ def worker(rank, world, port, case, q):
             out.update(L=rel(L, Lo), lml=abs(lml - lml_o) / abs(lml_o), alpha=rel(host(gp.alpha)[:n], orc.gpr_alpha(Lo, y)),
                        mean=rel(mean, mean_o), cov=rel(cov, cov_o), shapes=(mean.shape, cov.shape),
                        var=max(rel(var_d, np.diagonal(cov_o)), rel(mean_d, mean_o)), mem=gp.resident_bytes,
-                       grid=(gp.P, gp.Q))
+                       grid=(gp.P, gp.Q), grouped=gp.grouped_launches)
             # the diagonal-block inverses every rank keeps must match the factor it keeps
             nb = 128
             worst = 0.0

@@ -23,6 +23,9 @@ def _check(outs, case, world):
         assert o["L"] < 1e-12 and o["dinv"] < 1e-9, o
         assert o["lml"] < 1e-11 and o["alpha"] < 1e-9 and o["grad"] < 1e-9, o
         assert o["mean"] < 1e-10 and o["cov"] < 1e-9 and o["var"] < 1e-9 and o["res"] < 1e-10, o
+    # delayed updates over enough tiles: the grouped launch (several tile columns in one product) must have run
+    if case.get("update_k", 2048) > case["block"] and case["n"] >= 10 * case["block"] and not case.get("grid"):
+        assert max(o["grouped"] for o in outs) > 0, [o["grouped"] for o in outs]
     return outs
 
 

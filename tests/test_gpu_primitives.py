@@ -104,6 +104,65 @@ def test_gemm_very_long_k_runs_in_chunks(rt, ta, tb):
     assert relerr(down(rt, dC, M, N), ref) < 1e-13
 
 
+@pytest.mark.parametrize("nb,ncols,K,M_extra", [(128, 5, 40, 0), (256, 7, 272, 100), (512, 12, 2048, 37)])
+def test_gemm_colblocks_matches_numpy(rt, nb, ncols, K, M_extra):
+    """The grouped trailing update of the sharded Cholesky: ONE launch over several nb-wide column blocks, each
+    landing in its own slab (leading dimension nb) that starts at its own first row; tiles above a slab's first
+    row are skipped and the slabs' other contents are untouched.  Checked against NumPy block by block."""
+    import torch
+    rng = np.random.default_rng(nb + ncols)
+    # local rows: the slabs start at rows 0, nb, 2 nb, ... of a row space of ncols * nb (+ a ragged piece) rows
+    R = ncols * nb - (nb - M_extra if M_extra else 0)
+    row0 = np.array([c * nb for c in range(ncols)], dtype=np.int32)
+    w_last = 70 if M_extra else nb                               # ragged last column block
+    N = (ncols - 1) * nb + w_last
+    heights = [(R - row0[c] + nb - 1) // nb * nb for c in range(ncols)]       # whole tiles high
+    offs, off = [], 64                                           # the store starts with an unrelated 64 doubles
+    for c in range(ncols):
+        offs.append(off - int(row0[c]) * nb)
+        off += heights[c] * nb
+    store_h = rng.standard_normal(off + 32)
+    A = rng.standard_normal((R, K))
+    B = rng.standard_normal((N, K))
+    dA, dB = up(rt, A), up(rt, B)
+    store = rt.torch.from_numpy(store_h.copy()).to(rt.dev)
+    d_off = rt.torch.tensor(offs, dtype=rt.torch.int64, device=rt.dev)
+    # bit 0 of a table entry: the slab starts with the column's diagonal tile (here: the even blocks)
+    d_row0 = rt.torch.from_numpy(row0 | (1 - np.arange(ncols, dtype=np.int32) % 2)).to(rt.dev)
+    first = 2 if ncols > 4 else 0                                # launch over column blocks first.. : row base = its first row
+    rb = int(row0[first])
+    Nl = N - first * nb
+    ok(rt.lib.gpx_gemm_colblocks(rt.h, R - rb, Nl, K, -1.0, C.c_void_p(dA.data_ptr() + 8 * rb * dA.shape[1]), dA.shape[1],
+                                 C.c_void_p(dB.data_ptr() + 8 * first * nb * dB.shape[1]), dB.shape[1], 1.0, P(store), nb, rb,
+                                 C.c_void_p(d_off.data_ptr() + 8 * first), C.c_void_p(d_row0.data_ptr() + 4 * first)))
+    rt.torch.cuda.synchronize()
+    got = store.cpu().numpy()
+    want = store_h.copy()
+
+    def live(c, i, w):
+        """columns of row i of block c that the launch writes: inside the slab's first nb rows (its diagonal tile)
+        the 128 x 128 tiles strictly above the diagonal are skipped"""
+        rel = i - int(row0[c])
+        return min(w, (rel // 128 + 1) * 128) if (rel < nb and c % 2 == 0) else w
+
+    for c in range(first, ncols):
+        w = nb if c < ncols - 1 else w_last
+        prod = A[row0[c]:] @ B[c * nb: c * nb + w].T
+        for i in range(row0[c], R):
+            o = offs[c] + i * nb
+            wl = live(c, i, w)
+            want[o: o + wl] -= prod[i - row0[c]][:wl]
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1e-13 * scale * max(1.0, K ** 0.5)
+    assert nb == 128 or any(live(c, int(row0[c]), nb) < nb for c in range(first, ncols))
+    untouched = np.ones(len(want), dtype=bool)
+    for c in range(first, ncols):
+        w = nb if c < ncols - 1 else w_last
+        for i in range(row0[c], R):
+            untouched[offs[c] + i * nb: offs[c] + i * nb + live(c, i, w)] = False
+    assert np.array_equal(got[untouched], store_h[untouched])
+
+
 # ----------------------------------------------------------------------------- Gram
 @pytest.mark.parametrize("kind,d", [("rbf", 1), ("rbf", 3), ("ard", 2), ("ard", 8), ("ard", 5)])
 @pytest.mark.parametrize("n1,n2", [(1, 1), (15, 50), (129, 257), (300, 300), (700, 1537), (1100, 512)])   # the last two: 512-column strips, several row blocks of the packed lower grid
