@@ -296,7 +296,8 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
     // column this process row does not own the diagonal tile of starts with a full tile below the diagonal)
     const int r0e = g.cb_row0[c];
     const int rel_last = g.cb_rowbase + bi * BM + BM - 1 - (r0e & ~1);   // last row of the tile, slab-relative
-    if (rel_last < ((r0e & 1) ? bj * BN - c * g.cb_nb : 0)) return;   // (workgroup-uniform, before any barrier)
+    // (workgroup-uniform, before any barrier; the skip works on 128 x 128 blocks whatever the tile size)
+    if (rel_last < 0 || ((r0e & 1) && (rel_last | 127) < ((bj * BN - c * g.cb_nb) & ~127))) return;
     g.D += g.cb_off[c] + (long)g.cb_rowbase * g.cb_nb - (long)c * g.cb_nb;
     g.Cin = g.D;
   }
@@ -655,8 +656,8 @@ int launch_cfg(hipStream_t s, const GemmDesc& g) {
   static const bool log_shapes = getenv("GPX_GEMM_LOG") != nullptr;   // development: one line per kernel launch
   auto log_launch = [&](const char* part, unsigned blocks) {
     if (log_shapes)
-      fprintf(stderr, "GEMMLOG %d %d %d lower=%d atri=%d btri=%d inplace=%d cfg=%d part=%s blocks=%u\n", g.M, g.N, g.K,
-              g.c_lower, g.a_tri, g.b_tri, g.inplace, TM * 10 + TN, part, blocks);
+      fprintf(stderr, "GEMMLOG %d %d %d lower=%d atri=%d btri=%d inplace=%d cfg=%d part=%s blocks=%u cb=%d\n", g.M, g.N, g.K,
+              g.c_lower, g.a_tri, g.b_tri, g.inplace, TM * 10 + TN, part, blocks, g.cb_off ? g.cb_nb : 0);
   };
   // pacing counters (one per super-tile, at the head of the workspace) for the main part of a long-K
   // launch in super-tile mode with plain operands

@@ -68,9 +68,16 @@ struct GramArgs {
   double sigma, diag_add;
   double* K; long ldk;
   int lower;
+  int nt;      // interior tiles: non-temporal stores (development switch GPX_GRAM_NT, see gpx_gram_launch)
   BetaArg sb;  // sqrt(beta_k / 2)
   double tab[EXP_TAB];  // sigma * 2^(j/64)
 };
+
+__device__ __forceinline__ void store_pair(double* p, double a, double b, bool nt) {
+  const v2d v = {a, b};
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p));
+  else *reinterpret_cast<v2d*>(p) = v;
+}
 
 // D > 0: compile-time dimension (unrolled, registers); D == 0: runtime d <= GPX_MAXD.
 // CP: column pairs per lane.  A workgroup owns GT_SUBS row sub-tiles (64 rows each) of one strip of
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(GT_THREADS) void gram_kernel(const GramArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < CP; ++q)
-          *reinterpret_cast<v2d*>(dst + q * GT_COLS) = (v2d){exp_neg_tab(s[q][0], stab), exp_neg_tab(s[q][1], stab)};
+          store_pair(dst + q * GT_COLS, exp_neg_tab(s[q][0], stab), exp_neg_tab(s[q][1], stab), a.nt != 0);
         dst += a.ldk;
       }
       continue;
@@ -243,6 +250,7 @@ struct TraceArgs {
   // gpx_lauum_upper leaves beside W = L^-1 in one n x n buffer.  The matrix is symmetric, so the sums are
   // the same; only the tile tests are mirrored.
   int upper; const double* kdiag;
+  int mode;          // development switch GPX_TRACE_MODE: 0 = round-2 interior loop (two rows in flight per wave)
   double* partials;  // [nblocks][nacc]
   BetaArg sb;        // sqrt(beta_k / 2): the squared differences below are beta_k diff_k^2 / 2 (the host doubles the sums)
   double tab[EXP_TAB];  // 2^(j/64): K_ij / sigma = exp_neg_tab(sum_k beta_k diff_k^2 / 2)
@@ -261,7 +269,7 @@ struct TraceCfg {
 };
 
 template <int D>
-__global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs a, int band_row0) {
+__global__ __launch_bounds__(GT_THREADS, (D > 0 ? 3 : 1)) void grad_trace_kernel(const TraceArgs a, int band_row0) {
   constexpr int SUBS = TraceCfg<D>::SUBS, DD = TraceCfg<D>::DD;
   __shared__ double sx1[SUBS * GT_ROWS * DD];
   __shared__ double sal[SUBS * GT_ROWS];
@@ -312,34 +320,64 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
                             r0 + GT_ROWS <= a.nr && c0 + GT_COLS <= a.nc;
       if (interior) {
         const double* src = a.Kinv + (long)(r0 + wid * 16) * a.ldk + c;
-#pragma unroll 2
-        for (int rr = 0; rr < 16; ++rr) {
-          const v2d q = *reinterpret_cast<const v2d*>(src);
-          src += a.ldk;
-          const int r = wid * 16 + rr;
-          const double ai = as[r];
-          double s0 = 0.0, s1 = 0.0;
-          double e0[DD], e1[DD];
+        // The accumulators acc[1..] are kept in HALF units (off-diagonal elements weigh 1, diagonal ones 1/2) and
+        // doubled once before the reduction -- exact in binary floating point -- so the weight 2 of the symmetric
+        // sum costs nothing per element; the products go into the accumulators by fma.  ~62 VALU instructions per
+        // element at d = 8 (74 in round 2); the kernel is bound by their issue rate.  Compiled for 3 waves per SIMD (168
+        // VGPRs, no spills): n = 65536 5.27 ms against 6.2 ms at 2 waves per SIMD; forcing 4 (128 VGPRs) spills -- 20 ms.
+        // (the RBF / ARD choice is made OUTSIDE the row loop: as a branch inside it the compiler carried both sets
+        // of accumulators through the loop with ~20 register moves per element)
+        v2d qn = *reinterpret_cast<const v2d*>(src);
+        if (a.nbeta == 1) {
+#pragma unroll 1
+          for (int rr = 0; rr < 16; ++rr) {
+            const v2d q = qn;
+            src += a.ldk;
+            if (rr < 15) qn = *reinterpret_cast<const v2d*>(src);   // next row's pair in flight under this row's arithmetic
+            const int r = wid * 16 + rr;
+            const double ai = as[r];
+            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-          for (int k = 0; k < DD; ++k) {
-            if (k < d) {
-              const double x = xs[r * d + k];
-              const double d0 = x - z0[k], d1 = x - z1[k];
-              e0[k] = d0 * d0;
-              e1[k] = d1 * d1;
-              s0 += e0[k];
-              s1 += e1[k];
+            for (int k = 0; k < DD; ++k) {
+              if (k < d) {
+                const double x = xs[r * d + k];
+                const double d0 = x - z0[k], d1 = x - z1[k];
+                s0 = fma(d0, d0, s0);
+                s1 = fma(d1, d1, s1);
+              }
             }
+            const double w0 = fma(ai, al0, -q[0]) * exp_neg_tab(s0, stab);
+            const double w1 = fma(ai, al1, -q[1]) * exp_neg_tab(s1, stab);
+            acc[1] += w0 + w1;
+            acc[2] = fma(w1, s1, fma(w0, s0, acc[2]));
           }
-          const double w0 = 2.0 * (ai * al0 - q[0]) * exp_neg_tab(s0, stab);
-          const double w1 = 2.0 * (ai * al1 - q[1]) * exp_neg_tab(s1, stab);
-          acc[1] += w0 + w1;
-          if (a.nbeta == 1) {
-            acc[2] += w0 * s0 + w1 * s1;
-          } else {
+        } else {
+#pragma unroll 1
+          for (int rr = 0; rr < 16; ++rr) {
+            const v2d q = qn;
+            src += a.ldk;
+            if (rr < 15) qn = *reinterpret_cast<const v2d*>(src);   // next row's pair in flight under this row's arithmetic
+            const int r = wid * 16 + rr;
+            const double ai = as[r];
+            double s0 = 0.0, s1 = 0.0;
+            double e0[DD], e1[DD];
+#pragma unroll
+            for (int k = 0; k < DD; ++k) {
+              if (k < d) {
+                const double x = xs[r * d + k];
+                const double d0 = x - z0[k], d1 = x - z1[k];
+                e0[k] = d0 * d0;
+                e1[k] = d1 * d1;
+                s0 += e0[k];
+                s1 += e1[k];
+              }
+            }
+            const double w0 = fma(ai, al0, -q[0]) * exp_neg_tab(s0, stab);
+            const double w1 = fma(ai, al1, -q[1]) * exp_neg_tab(s1, stab);
+            acc[1] += w0 + w1;
 #pragma unroll
             for (int k = 0; k < DD; ++k)
-              if (k < d) acc[2 + k] += w0 * e0[k] + w1 * e1[k];
+              if (k < d) acc[2 + k] = fma(w1, e1[k], fma(w0, e0[k], acc[2 + k]));
           }
         }
         continue;
@@ -378,8 +416,8 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
         }
         const double A0 = v0 ? ai * al0 - q0 : 0.0;
         const double A1 = v1 ? ai * al1 - q1 : 0.0;
-        const double w0 = v0 ? (gc == gr ? 1.0 : 2.0) * A0 * exp_neg_tab(s0, stab) : 0.0;
-        const double w1 = v1 ? (gc + 1 == gr ? 1.0 : 2.0) * A1 * exp_neg_tab(s1, stab) : 0.0;
+        const double w0 = v0 ? (gc == gr ? 0.5 : 1.0) * A0 * exp_neg_tab(s0, stab) : 0.0;   // half units, see above
+        const double w1 = v1 ? (gc + 1 == gr ? 0.5 : 1.0) * A1 * exp_neg_tab(s1, stab) : 0.0;
         if (v0 && gc == gr) acc[0] += A0;
         if (v1 && gc + 1 == gr) acc[0] += A1;
         acc[1] += w0 + w1;
@@ -395,7 +433,7 @@ __global__ __launch_bounds__(GT_THREADS) void grad_trace_kernel(const TraceArgs 
   }
   // wave reduction (fixed order), then 4 waves through LDS
   for (int q = 0; q < nacc; ++q) {
-    double v = acc[q];
+    double v = q == 0 ? acc[q] : 2.0 * acc[q];   // acc[1..] were kept in half units
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if (lane == 0) sred[wid][q] = v;
@@ -445,6 +483,11 @@ int gpx_gram_launch(hipStream_t s, const double* X1, int n1, long ldx1, const do
   a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1;
   a.X2 = X2; a.ldx2 = ldx2; a.n2 = n2;
   a.d = d; a.sigma = sigma; a.diag_add = diag_add; a.K = K; a.ldk = ldk; a.lower = uplo == GPX_LOWER;
+  // The matrix is written once and not read back by this kernel; non-temporal stores (meant to keep the streamed
+  // lines from evicting the rows of X that every workgroup re-reads through its XCD's L2) were measured and changed
+  // nothing: 3.771 against 3.778 ms lower, 7.06 against 7.02 ms full at n = 65536.  Off by default.
+  static const int nt = [] { const char* e = getenv("GPX_GRAM_NT"); return e ? atoi(e) : 0; }();   // development switch
+  a.nt = nt;
   for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(0.5 * hb.b[k]) : 0.0;
   for (int j = 0; j < EXP_TAB; ++j) a.tab[j] = (double)((long double)sigma * exp2l((long double)j / EXP_TAB));
   dispatch_d(d, [&](auto D) {
@@ -486,6 +529,8 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int n
                           const double* kdiag) {
   TraceArgs a;
   a.upper = kdiag != nullptr; a.kdiag = kdiag;
+  static const int mode = [] { const char* e = getenv("GPX_TRACE_MODE"); return e ? atoi(e) : 1; }();   // development switch
+  a.mode = mode;
   a.X = X; a.ldx = ldx; a.nr = nr; a.nc = nc; a.roff = roff; a.coff = coff; a.d = d; a.nbeta = nbeta;
   a.sigma = sigma; a.alpha = alpha; a.Kinv = Kinv; a.ldk = ldk; a.partials = red;
   for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(0.5 * hb.b[k]) : 0.0;

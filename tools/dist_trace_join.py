@@ -31,11 +31,11 @@ for sh, t, fl, nk, ph in logical:
     M, N, K = sh["M"], sh["N"], sh["K"]
     kc = "K<=128" if K <= 128 else "K<=512" if K <= 512 else "K<=2048" if K <= 2048 else "K<=8192" if K <= 8192 else "K>8192"
     nc = "N<=128" if N <= 128 else "N<=512" if N <= 512 else "N<=2048" if N <= 2048 else "N>2048"
-    key = "%-16s %-8s %-8s tri=%d%d low=%d" % (ph[6:], kc, nc, sh["atri"], sh["btri"], sh["lower"])
+    key = "%-16s %-8s %-8s tri=%d%d low=%d%s" % (ph[6:], kc, nc, sh["atri"], sh["btri"], sh["lower"], " grouped" if sh["cb"] else "")
     c = cls.setdefault(key, [0, 0.0, 0.0])
     c[0] += 1; c[1] += t; c[2] += fl
     if ph == "timed-potrf" and K >= 2048:
-        big.setdefault((M, N, K), []).append(t)
+        big.setdefault((M, N, K, fl), []).append(t)
 tot = collections.defaultdict(lambda: [0.0, 0.0])
 for k in sorted(cls):
     c = cls[k]
@@ -59,6 +59,6 @@ if lk:
     ts = sorted(dur(r) for r in lk)
     print("leaf / chain kernels: %d, average %.1f us, median %.1f us, max %.1f us" % (len(ts), 1e6 * sum(ts) / len(ts), 1e6 * ts[len(ts) // 2], 1e6 * ts[-1]))
 print("potrf launches with K >= 2048 (parts merged), every 8th:")
-for i, ((M, N, K), ts) in enumerate(big.items()):
+for i, ((M, N, K, fl), ts) in enumerate(big.items()):
     if i % 8 == 0:
-        print("  %6d %5d %6d x%d  %9.1f us  %6.1f TF" % (M, N, K, len(ts), 1e6 * sum(ts) / len(ts), 2.0 * M * N * K / (sum(ts) / len(ts)) / 1e12))
+        print("  %6d %5d %6d x%d  %9.1f us  %6.1f TF" % (M, N, K, len(ts), 1e6 * sum(ts) / len(ts), fl / (sum(ts) / len(ts)) / 1e12))

@@ -12,7 +12,26 @@ this way can exceed the 78.6 TFLOP/s fp64 MFMA peak."""
 PEAK_TF = 78.6
 
 
-def launch_flops(M, N, K, lower, atri, btri):
+def colblock_flops(M, N, K, nb):
+    """Grouped trailing update (gpx_gemm_colblocks) on ONE rank (P = 1): column block c starts c * nb rows below the
+    launch's first row and only the 128-blocks on or below its diagonal tile's diagonal are computed."""
+    fl, c = 0.0, 0
+    while c * nb < N:
+        w = min(nb, N - c * nb)
+        rows = M - c * nb
+        if rows > 0:
+            h = min(nb, rows)                               # the slab's diagonal tile: lower 128-blocks only
+            nblk = (min(h, w) + 127) // 128
+            diag = sum(min(128, h - 128 * i) * min(w, 128 * (i + 1)) for i in range(nblk))
+            diag += max(0, h - 128 * nblk) * w
+            fl += 2.0 * K * (diag + max(0, rows - h) * w)
+        c += 1
+    return fl
+
+
+def launch_flops(M, N, K, lower, atri, btri, cb=0):
+    if cb:
+        return colblock_flops(M, N, K, cb)
     fl = 2.0 * M * N * K
     if lower and atri and btri:
         return fl / 6.0
@@ -28,7 +47,7 @@ def parse_shape(s):
     kv = dict(w.split("=") for w in s[4:] if "=" in w)
     return dict(M=int(s[1]), N=int(s[2]), K=int(s[3]), lower=int(kv["lower"]), atri=int(kv["atri"]),
                 btri=int(kv["btri"]), inplace=int(kv.get("inplace", 0)), cfg=kv.get("cfg", "?"),
-                part=kv.get("part", "main"), blocks=int(kv.get("blocks", 0)))
+                part=kv.get("part", "main"), blocks=int(kv.get("blocks", 0)), cb=int(kv.get("cb", 0)))
 
 
 def merge_parts(entries):
@@ -40,5 +59,5 @@ def merge_parts(entries):
             m = out[-1]
             out[-1] = (m[0], m[1] + t, m[2], m[3] + 1, m[4])
         else:
-            out.append((sh, t, launch_flops(sh["M"], sh["N"], sh["K"], sh["lower"], sh["atri"], sh["btri"]), 1, extra))
+            out.append((sh, t, launch_flops(sh["M"], sh["N"], sh["K"], sh["lower"], sh["atri"], sh["btri"], sh["cb"]), 1, extra))
     return out
