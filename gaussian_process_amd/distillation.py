@@ -16,10 +16,14 @@ MI355X through the inherited EP machinery (expectation_propagation.py of this pa
                                                   to the 2n x 2n K); here the jitter has the size of K
                                                   and the two trace terms per parameter are returned.
 """
+import ctypes as C
+
 import numpy as np
 from scipy.special import log_ndtr
 from sklearn.utils import check_X_y
 
+from . import _lib
+from .device import on_device, ptr
 from .expectation_propagation import GaussianProcessExpectationPropagation
 
 
@@ -49,9 +53,18 @@ class GaussianProcessDistillation(GaussianProcessExpectationPropagation):
         self.fit(self.Xtr, self.ytr, self.str)
 
     def posterior(self, X):
+        if hasattr(self.cov, "gram_params"):
+            return self._posterior_device(X)           # K* stacked on the device, see _stack_cross_cov
         Ks_ = self._cross_cov(X)
         Kss = self.cov(X, diag=True).K
         return self._posterior(np.vstack([Ks_, self.rho * Ks_]), Kss)
+
+    def _stack_cross_cov(self, Ks_top, m):
+        """distillation.py:41-42 on the device: rows n..2n-1 of the 2n x m buffer <- rho * K(Xtr, X*)."""
+        n = self.n
+        Ks_top[n:2 * n, :m].copy_(Ks_top[:n, :m])
+        Ks_top[n:2 * n, :m].mul_(float(self.rho))
+        return Ks_top, 2 * n
 
     def log_marginal_likelihood(self, eps=1e-7, splitted_terms=False):
         n = self.n
@@ -73,6 +86,8 @@ class GaussianProcessDistillation(GaussianProcessExpectationPropagation):
         return terms if splitted_terms else sum(terms)
 
     def grad_log_marginal_likelihood(self, splitted_terms=False):
+        if hasattr(self.cov, "gram_params"):
+            return self._grad_device(splitted_terms)
         n = self.n
         kernel = self.cov(self.Xtr)
         Kt = self._task_kernel()
@@ -84,3 +99,65 @@ class GaussianProcessDistillation(GaussianProcessExpectationPropagation):
             K_grads["cov__" + name] = np.kron(Kt, v)
         return {k: v if splitted_terms else sum(v)
                 for k, v in self._grad_log_marginal_likelihood(K, K_grads).items()}
+
+    @on_device
+    def _grad_device(self, splitted_terms):
+        """distillation.py:65-81 with every contraction on the device.  All derivative matrices are Kronecker
+        products kron(T, v) of a symmetric 2 x 2 task matrix T with an n x n matrix v of the base kernel (K_ itself
+        for rho, dK_/dtheta for the kernel parameters, the identity block for sigma), so with b = [b0; b1] and
+        U^T U = [[M00, M01], [M10, M11]] (expectation_propagation.py:162-165 on the 2n x 2n system)
+
+            b^T kron(T, v) b       = sum_i lambda_i c_i^T v c_i,   T = sum_i lambda_i u_i u_i^T,  c_i = u_i0 b0 + u_i1 b1
+            sum(U^T U o kron(T, v)) = sum(M_T o v),                 M_T = T00 M00 + T01 (M01 + M10) + T11 M11
+
+        and both are sums the fused trace kernel of the regression gradient forms from X without ever building v
+        (gpx_grad_trace with alpha = c_i and a zero matrix, resp. alpha = 0 and M_T).  Round 2 downloaded the
+        2n x 2n U^T U and contracted against host Kronecker planes (four 2n x 2n host matrices per parameter).
+        Parity-unpinned by necessity (the reference raises here, see the module docstring); checked against NumPy
+        in tests/test_gpu_ep.py."""
+        dv = self._dv
+        rt, n, N = dv["rt"], self.n, dv["n"]
+        rt.bind_stream()
+        lib = rt.lib
+        UtU = self._UtU_device(dv)                                    # N x N, device, full symmetric
+        nu_d = rt.upload_vector(self.nu_tilde)
+        t1, t2 = rt.vector(N), rt.vector(N)
+        _lib.check(lib.gpx_gemv(rt.h, 0, N, N, ptr(dv["K"]), dv["K"].shape[1], ptr(nu_d), ptr(t1)), "gpx_gemv")
+        _lib.check(lib.gpx_gemv(rt.h, 0, N, N, ptr(UtU), UtU.shape[1], ptr(t1), ptr(t2)), "gpx_gemv")
+        b = self.nu_tilde - rt.download(t2[:N])
+        kind, sigma, beta = self.cov.gram_params(self.dim)
+        beta_arr, beta_p = _lib.host_doubles(beta)
+        dX = rt.upload_matrix(np.ascontiguousarray(self.Xtr, dtype=np.float64))
+        ng = 2 + len(beta_arr)
+        Z, M = rt.matrix(n, n), rt.matrix(n, n)
+        Z.zero_()
+        zero_vec = rt.vector(n, zero=True)
+
+        def traces(alpha_d, mat):
+            out = (C.c_double * ng)()
+            _lib.check(lib.gpx_grad_trace(rt.h, kind, ptr(dX), n, dX.shape[1], self.dim, sigma, beta_p, ptr(alpha_d),
+                                          ptr(mat), mat.shape[1], None, C.cast(out, C.POINTER(C.c_double))), "gpx_grad_trace")
+            return np.array(list(out))
+
+        def pair(T):
+            """[1/2 b^T kron(T, .) b, 1/2 sum(U^T U o kron(T, .))] for . = I, dK_/dsigma, dK_/dbeta (one vector each)"""
+            lam, U = np.linalg.eigh(np.asarray(T, dtype=np.float64))
+            first = np.zeros(ng)
+            for i in range(2):
+                if lam[i] != 0.0:
+                    first += lam[i] * traces(rt.upload_vector(U[0, i] * b[:n] + U[1, i] * b[n:]), Z)
+            M[:n, :n].copy_(UtU[:n, :n])
+            M[:n, :n].mul_(float(T[0][0]))
+            M[:n, :n].add_(UtU[:n, n:N] + UtU[n:N, :n], alpha=float(T[0][1]))
+            M[:n, :n].add_(UtU[n:N, n:N], alpha=float(T[1][1]))
+            return first, -traces(zero_vec, M)
+
+        Kt = self._task_kernel()
+        f_cov, s_cov = pair(Kt)
+        f_rho, s_rho = pair([[0.0, 1.0], [1.0, 0.0]])
+        f_sig, s_sig = pair([[0.0, 0.0], [0.0, 1.0]])
+        # entry 0: v = I; entry 1: v = K_ / sigma_k (dK_/dsigma); entries 2..: dK_/dbeta
+        out = {"rho": [sigma * f_rho[1], sigma * s_rho[1]], "sigma": [f_sig[0], s_sig[0]],
+               "cov__sigma": [f_cov[1], s_cov[1]],
+               "cov__beta": [f_cov[2], s_cov[2]] if len(beta_arr) == 1 else [f_cov[2:].copy(), s_cov[2:].copy()]}
+        return {k: v if splitted_terms else np.sum(v, axis=0) for k, v in out.items()}

@@ -44,7 +44,7 @@ from .grid2d import Grid2D, default_grid
 def default_block(world):
     """Tile size nb per world size: wide tiles keep the local GEMMs efficient, narrow ones shorten the
     factorisation chain (its length is n / nb steps whatever the number of ranks)."""
-    return {1: 2048, 2: 2048, 4: 1024, 8: 512}.get(world, 1024)
+    return {1: 2048, 2: 1024, 4: 1024, 8: 512}.get(world, 1024)
 
 
 class _Done:
@@ -201,7 +201,11 @@ class DistributedGP:
         self.p, self.q = divmod(rank, self.Q)
         # K the delayed trailing updates aim for: a tile column absorbs update_k / block panels in one
         # GEMM (K = block alone runs 15-20 % slower on the MFMA kernel and rewrites the column every step)
-        self.update_k = update_k or {1: 8192, 2: 4096}.get(world, 2048)
+        # (K = 4096 and 8192 run alike on one rank -- potrf 1474 against 1472 ms at n = 65536 -- and the ring of
+        # pending panels is half as large)
+        # Two ranks (2 x 1): tile 1024 and K = 2048 keep the rings and the staging below half of the rank's share of
+        # the matrix (the column ring holds ALL tile columns on a P x 1 grid).
+        self.update_k = update_k or {1: 4096}.get(world, 2048)
         # columns of Ky^-1 per gradient slab (each slab is one forward + one backward solve)
         self.grad_block = grad_block or 4096
         if many_rhs:
@@ -367,18 +371,26 @@ class DistributedGP:
         self.g_upd = max(1, self.update_k // nb)
         self.G = self.g_upd + 2
         self.RB = ops.empty(max(nlr, 1) * nb, self.G * nb)
-        self.CB = ops.empty(max(nlc, 1) * nb, self.G * nb)
-        self.rowstg = [ops.empty(max(nlr, 1) * nb * nb) for _ in range(2)]
+        # On a 1 x 1 grid the panel by local row and the panel by local column are the same tiles in the same
+        # places: one ring serves as both operands of the trailing update.
+        self.cb_is_rb = self.P == 1 and self.Q == 1
+        self.CB = self.RB if self.cb_is_rb else ops.empty(max(nlc, 1) * nb, self.G * nb)
+        # Staging of the collectives, ONE buffer each (round 2 kept two, by panel parity).  Panel k + 1's collectives
+        # are issued after _file_panel(k) has enqueued its copies out of the staging buffers, and every collective
+        # (and the forwarding stream) starts by waiting for what the compute stream had enqueued at that moment, so a
+        # buffer is never rewritten before its last reader -- on the sender as on the receivers, each of which
+        # orders its own side the same way.  Allocated only for the communicators that carry traffic.
+        self.rowstg = ops.empty(max(nlr, 1) * nb * nb) if self.rc else None
         cmax = max([g.transposed_max(q, k) for k in range(g.T)] + [1])
-        # both double-buffered by panel parity; flat, so that the (P x count) view of any panel is contiguous
-        self.tsend = [ops.empty(cmax * nb * nb) for _ in range(2)]
-        self.trecv = [ops.empty(self.P * cmax * nb * nb) for _ in range(2)]
-        self.dstg = [ops.empty(nb * nb + dper) for _ in range(2)]
+        # flat, so that the (P x count) view of any panel is contiguous
+        self.tsend = ops.empty(cmax * nb * nb) if self.cc else None
+        self.trecv = ops.empty(self.P * cmax * nb * nb) if self.cc else None
+        self.dstg = ops.empty(nb * nb + dper) if self.cc else None
         self._ws = {}
+        numel = lambda b: 0 if b is None else b.numel()
         self.resident_bytes = dict(matrix=8 * total,
-                                   panels=8 * (self.RB.numel() + self.CB.numel() + 2 * self.rowstg[0].numel()
-                                               + 2 * self.tsend[0].numel() + 2 * self.trecv[0].numel()
-                                               + 2 * self.dstg[0].numel()),
+                                   panels=8 * (self.RB.numel() + (0 if self.cb_is_rb else self.CB.numel()) + numel(self.rowstg)
+                                               + numel(self.tsend) + numel(self.trecv) + numel(self.dstg)),
                                    lower_over_world=8 * g.lower_elems() // self.world)
 
     def set_theta(self, kind, sigma, beta, noise):
@@ -512,7 +524,7 @@ class DistributedGP:
             if has_panel and self.cc:
                 # the broadcast down the process column leaves as soon as the tile is factored; the update of
                 # the rows below (next) runs under it
-                dst = self.dstg[k % 2]
+                dst = self.dstg
                 if mine:
                     dst[: nb * nb].view(nb, nb).copy_(slab[:nb])
                     dst[nb * nb:].copy_(self.dinv[k])
@@ -541,7 +553,7 @@ class DistributedGP:
                 start = nb if p == pk else 0
                 piece = self.slabs[k][start: start + ntiles * nb]          # whole tiles (slabs are padded)
             else:
-                piece = self.rowstg[k % 2][: ntiles * nb * nb].view(ntiles * nb, nb)
+                piece = self.rowstg[: ntiles * nb * nb].view(ntiles * nb, nb)
             if self.rc:
                 h_row = self._bcast(piece.reshape(-1)[: R * nb], self._grank(p, qk), self.row_group, async_op=True)
         out = dict(R=R, piece=piece, h_row=h_row, cnt_max=g.transposed_max(q, k), h_T=_Done())
@@ -550,10 +562,10 @@ class DistributedGP:
             cm = out["cnt_max"]
             with self._forwarding():
                 h_row.wait()
-                send = self.tsend[k % 2]
+                send = self.tsend
                 if cnt > 0:
                     send[: cnt * nb * nb].view(cnt, nb, nb).copy_(piece.view(ntiles, nb, nb)[t0::step][:cnt])
-                out["h_T"] = self._all_gather(self.trecv[k % 2][: P * cm * nb * nb].view(P, cm * nb * nb),
+                out["h_T"] = self._all_gather(self.trecv[: P * cm * nb * nb].view(P, cm * nb * nb),
                                               send[: cm * nb * nb], self.col_group, async_op=True)
         return out
 
@@ -573,6 +585,8 @@ class DistributedGP:
         if h["cnt_max"] == 0:
             return
         h["h_T"].wait()
+        if self.cb_is_rb:
+            return                      # 1 x 1 grid: the rows just filed are the column tiles as well
         nlc = self.CB.shape[0] // nb
         CBt = self.CB.view(nlc, nb, self.G * nb)
         stride = g.L // Q
@@ -583,7 +597,7 @@ class DistributedGP:
             first = g.local_rows(src, k + 1)[t0]                       # a tile index I with I mod Q == q
             if self.cc:
                 cm = h["cnt_max"]
-                tiles = self.trecv[k % 2][: P * cm * nb * nb].view(P, cm * nb * nb)[src, : cnt * nb * nb].view(cnt, nb, nb)
+                tiles = self.trecv[: P * cm * nb * nb].view(P, cm * nb * nb)[src, : cnt * nb * nb].view(cnt, nb, nb)
             else:
                 tiles = h["piece"].view(-1, nb, nb)[t0::step][:cnt]
             CBt[first // Q:: stride][:cnt, :, cols].copy_(tiles)

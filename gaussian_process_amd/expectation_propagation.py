@@ -8,7 +8,9 @@ each) come back per sweep for the convergence test.
   site-update sweep            expectation_propagation.py:72-88         -> gpx_ep_sweep
   init + per-sweep recompute   expectation_propagation.py:61-65, 90-94  -> gpx_ep_recompute
   w, z after convergence       expectation_propagation.py:107-108       -> gpx_gemv + gpx_trsm
-  _posterior                   expectation_propagation.py:115-119       -> gpx_trsm (+ host sums)
+  posterior                    expectation_propagation.py:110-119       -> gpx_gram + gpx_gemv + gpx_trsm + gpx_colsumsq_sub
+                                                                           (K*, S o K*, the solve and the column sums on the
+                                                                           device: X* up, two m-vectors down)
   LML terms t0, t3             expectation_propagation.py:133, 136-137  -> diag(L), gpx_trsm
   gradient U = L^-1 diag(S)    expectation_propagation.py:162-166       -> gpx_trsm + gpx_gemm
 
@@ -202,9 +204,66 @@ class GaussianProcessExpectationPropagation(ClassifierMixin, BayesEstimator):
         return self.cov(self.Xtr, X).K
 
     def posterior(self, X):
+        if hasattr(self.cov, "gram_params"):
+            return self._posterior_device(X)
         Ks = self._cross_cov(X)
         Kss = self.cov(X, diag=True).K
         return self._posterior(Ks, Kss)
+
+    # number of test points per device batch of posterior(): n x batch doubles of HBM
+    POSTERIOR_BATCH = 8192
+
+    def _stack_cross_cov(self, Ks_top, m):
+        """Hook for subclasses whose prior is larger than K(Xtr, Xtr) (Distillation stacks [K*; rho K*]).
+        Ks_top: the device matrix whose first n rows hold K(Xtr, X*).  Returns (matrix, rows)."""
+        return Ks_top, self.n
+
+    @on_device
+    def _posterior_device(self, X):
+        """expectation_propagation.py:110-119 without a round trip of the n x m matrices: one upload of X*
+        (m x d), K* built on the device (gpx_gram), mean = K*^T (nu - z) (gpx_gemv), V = L^-1 (S o K*) (row scaling
+        + gpx_trsm), var = K** - colsum(V^2) (gpx_colsumsq_sub; K** = sigma on the diagonal of a stationary kernel,
+        kernels.py:41-43), one download of the two m-vectors.  Round 2 built K* on the device, downloaded it, scaled
+        it on the host, uploaded it again and downloaded V: three n x m bus trips per call."""
+        X = np.ascontiguousarray(np.asarray(X), dtype=np.float64)
+        assert X.ndim == 2 and X.shape[1] == self.dim
+        dv = self._dv
+        rt, N = dv["rt"], dv["n"]              # N: order of the EP system (n, or 2 n under distillation.py)
+        rt.bind_stream()
+        lib, torch = rt.lib, rt.torch
+        kind, sigma, beta = self.cov.gram_params(self.dim)
+        _, beta_p = _keep = _lib.host_doubles(beta)
+        if "Xtr" not in dv:
+            dv["Xtr"] = rt.upload_matrix(np.ascontiguousarray(self.Xtr, dtype=np.float64))
+            dv["S_dev"] = rt.upload_vector(self.S.ravel())
+            dv["nu_minus_z"] = rt.upload_vector(self.nu_tilde - self.z)
+        dX = dv["Xtr"]
+        means, vars_ = [], []
+        for i0 in range(0, X.shape[0], self.POSTERIOR_BATCH):
+            Xb = X[i0:i0 + self.POSTERIOR_BATCH]
+            m = Xb.shape[0]
+            dXs = rt.upload_matrix(Xb)
+            buf = dv.get("post_buf")
+            if buf is None or buf.shape[1] < max(32, ((m + 31) // 32) * 32):
+                buf = dv["post_buf"] = rt.matrix(N, m)
+            ld = buf.shape[1]
+            _lib.check(lib.gpx_gram(rt.h, kind, ptr(dX), self.n, dX.shape[1], ptr(dXs), m, dXs.shape[1], self.dim, sigma,
+                                    beta_p, 0.0, ptr(buf), ld, _lib.GPX_FULL), "gpx_gram")
+            Ks, rows = self._stack_cross_cov(buf, m)
+            assert rows == N
+            mean, var = rt.vector(m), rt.vector(m)
+            _lib.check(lib.gpx_gemv(rt.h, 1, N, m, ptr(Ks), ld, ptr(dv["nu_minus_z"]), ptr(mean)), "gpx_gemv")
+            Ks[:N, :m].mul_(dv["S_dev"][:N].unsqueeze(1))                      # S o K* (rows scaled in place)
+            _lib.check(lib.gpx_trsm(rt.h, 0, N, m, ptr(dv["B"]), dv["B"].shape[1], ptr(dv["dinv"]), ptr(Ks), ld), "gpx_trsm")
+            _lib.check(lib.gpx_colsumsq_sub(rt.h, N, m, ptr(Ks), ld, float(sigma), ptr(var)), "gpx_colsumsq_sub")
+            means.append(rt.download(mean[:m]).copy())
+            vars_.append(rt.download(var[:m]).copy())
+        mean, var = np.concatenate(means), np.concatenate(vars_)
+        bad = ~np.isfinite(X).all(axis=1)      # the device exp drops NaNs (kernels._nan_rows); NumPy's propagates them
+        if bad.any():
+            mean[bad] = np.nan
+            var[bad] = np.nan
+        return mean, var
 
     @on_device
     def _posterior(self, Ks, Kss):

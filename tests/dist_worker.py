@@ -58,7 +58,14 @@ def worker(rank, world, port, case, q):
                            grad_block=case.get("grad_block", 256), grid=grid,
                            force_collectives=bool(case.get("force_collectives")), many_rhs=case.get("many_rhs"))
         out = {"rank": rank}
-        if case.get("estimator"):
+        if case.get("alloc_only"):
+            # footprint only: the resident slabs and the panel workspaces as fit() would allocate them
+            from gaussian_process_amd.distributed import default_block
+            gp = DistributedGP(ops, dist, rank, world, block=case.get("block") or default_block(world), grid=grid,
+                               update_k=case.get("update_k"))
+            gp.allocate(X, y, kind, sigma, beta, noise)
+            out.update(mem=gp.resident_bytes, nb=gp.nb, G=gp.G, grid=(gp.P, gp.Q))
+        elif case.get("estimator"):
             # the reference's estimator interface over the ranks (distributed_regression.py)
             from gaussian_process_amd import ARD, RBF
             from gaussian_process_amd.distributed_regression import DistributedGaussianProcessRegression as DGPR

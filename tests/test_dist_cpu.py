@@ -76,6 +76,21 @@ def test_resident_matrix_is_sharded():
         assert mem["matrix"] >= 0.9 * mem["lower_over_world"], mem
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_panel_workspaces_stay_below_half_of_the_matrix(world):
+    """with the default tile / update-K choices the rings of pending panels and the staging
+    buffers of the collectives take at most half of a rank's share of the matrix on one and two ranks (round 2:
+    19.3 GB beside 17.7 GB at world 1).  Same tile COUNT as the headline (n / nb = 32 resp. 64 tiles), scaled down
+    8-fold: the ratio depends only on n / nb, the update K / nb and the grid."""
+    from gaussian_process_amd.distributed import default_block
+    scale = 8
+    case = dict(n=65536 // scale, m=3, d=2, block=default_block(world) // scale, kind="ard", alloc_only=True)
+    # (update_k scales with the tile: the defaults are 2 tiles per update on one and two ranks)
+    outs = _run(world, dict(case, update_k={1: 4096, 2: 2048}[world] // scale))
+    for o in outs:
+        assert o["mem"]["panels"] <= 0.5 * o["mem"]["matrix"], o
+
+
 def test_world2_not_positive_definite_reported_on_every_rank():
     # duplicated-point Gram with negative "noise": first failing minor is rank-independent
     outs = _run(2, dict(n=400, m=4, d=2, block=128, kind="ard", noise=-0.5, expect_fail=True))

@@ -182,6 +182,19 @@ def test_distillation_matches_reference(name):
     dK = np.kron(np.array([[0.0, 1.0], [1.0, 0.0]]), K_)
     assert abs(grads["rho"][0] - 0.5 * b @ dK @ b) < 1e-7 * max(1.0, abs(0.5 * b @ dK @ b))
     assert abs(grads["rho"][1] - 0.5 * np.trace(U.T @ U @ dK)) < 1e-7 * max(1.0, abs(0.5 * np.trace(U.T @ U @ dK)))
+    # the other parameters: the Kronecker planes of distillation.py:70-79 built on the host (the device path never forms them)
+    from oracle import gp_oracle as O
+    _, dsig, dbeta = O.rbf_cov(g["Xtr"], None, 1.0, 1.0, want_grad=True)
+    Kt = np.array([[1, rho], [rho, 1]])
+    planes = {"sigma": np.kron(np.array([[0.0, 0.0], [0.0, 1.0]]), np.eye(n)), "cov__sigma": np.kron(Kt, dsig),
+              "cov__beta": np.kron(Kt, dbeta)}
+    UtU = U.T @ U
+    for name, v in planes.items():
+        want = [0.5 * b @ v @ b, 0.5 * np.sum(UtU * v.T)]
+        for i in range(2):
+            assert abs(grads[name][i] - want[i]) < 1e-7 * max(1.0, abs(want[i])), (name, i, grads[name][i], want[i])
+    total = gpd.grad_log_marginal_likelihood()
+    assert abs(total["cov__beta"] - sum(grads["cov__beta"])) < 1e-12 * max(1.0, abs(total["cov__beta"]))
     # public API, RNG-driven site order
     np.random.seed(0)
     pub = GaussianProcessDistillation(cov=RBF(1, 1), sigma=sigma, rho=rho)
