@@ -245,10 +245,17 @@ __global__ __launch_bounds__(NTHREADS, (TM * TN >= 16 ? 2 : (TM * TN >= 8 ? 3 : 
   GemmDesc g = gin;
   if (gin.batch > 1) {   // uniform: this workgroup's product of the batch
     const long z = blockIdx.y;
-    g.A += z * gin.stride_a;
-    g.B += z * gin.stride_b;
-    g.D += z * gin.stride_d;
-    if (g.Cin != nullptr) g.Cin += z * gin.stride_d;
+    long oa = z * gin.stride_a, ob = z * gin.stride_b, od = z * gin.stride_d;
+    if (gin.batch_inner > 0) {   // two-level batch, see GemmDesc
+      const long zi = z % gin.batch_inner, zo = z / gin.batch_inner;
+      oa = zi * gin.stride_a + zo * gin.stride2_a;
+      ob = zi * gin.stride_b + zo * gin.stride2_b;
+      od = zi * gin.stride_d + zo * gin.stride2_d;
+    }
+    g.A += oa;
+    g.B += ob;
+    g.D += od;
+    if (g.Cin != nullptr) g.Cin += od;
   }
   constexpr int BM = 32 * TM, BN = 32 * TN;
   typedef Tile<ALAY, BM> TA;

@@ -278,9 +278,44 @@ constexpr size_t RED_USABLE = GPX_RED_ELEMS - RED_SCALARS;
 
 // B <- L^-1 B / L^-T B: one right-hand side goes to the streaming TRSV (trsv.hip), more to the
 // recursive MFMA TRSM.
+// Block inverses for the single-right-hand-side solves of one factor (trsv.hip), in the handle's grow-only
+// workspace.  Returns the workspace, or nullptr when n is below the threshold or the allocation fails (the
+// recursive solve is used then).
+double* trsv_prepare(gpx_handle* h, int n, const double* L, long ldl, const double* dinv) {
+  static const long min_n = [] {
+    const char* e = getenv("GPX_TRSV_BLOCKINV_MIN");   // development override; 0 disables the block-inverse path
+    return e ? atol(e) : (long)GPX_TRSV_BLOCKINV_MIN;
+  }();
+  if (min_n <= 0 || n < min_n) return nullptr;
+  const size_t need = gpx_trsv_blockinv_elems(n);
+  if (need > h->trsv_ws_elems) {
+    if (h->trsv_ws) {
+      (void)hipStreamSynchronize(h->stream);   // earlier solves may still read the old buffer
+      (void)hipFree(h->trsv_ws);
+    }
+    h->trsv_ws = nullptr;
+    h->trsv_ws_elems = 0;
+    if (hipMalloc(&h->trsv_ws, need * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      h->trsv_ws = nullptr;
+      return nullptr;
+    }
+    h->trsv_ws_elems = need;
+  }
+  if (gpx_trsv_blockinv_prepare(h->stream, n, L, ldl, dinv, h->trsv_ws) != 0) return nullptr;
+  return h->trsv_ws;
+}
+
+// one right-hand side with the block inverses already prepared for this factor (ws from trsv_prepare, may be null)
+int trsv_prepared(gpx_handle* h, double* ws, int trans, int n, const double* L, long ldl, const double* dinv, double* x,
+                  long incx) {
+  if (ws) return gpx_trsv_blockinv_solve(h->stream, trans, n, L, ldl, dinv, ws, x, incx, h->red, RED_USABLE);
+  return gpx_trsv_launch(h->stream, trans, n, L, ldl, dinv, x, incx, h->red, RED_USABLE);
+}
+
 int solve_lower(gpx_handle* h, int trans, int n, int m, const double* L, long ldl, const double* dinv,
                 double* B, long ldb) {
-  if (m == 1) return gpx_trsv_launch(h->stream, trans, n, L, ldl, dinv, B, ldb, h->red, RED_USABLE);
+  if (m == 1) return trsv_prepared(h, trsv_prepare(h, n, L, ldl, dinv), trans, n, L, ldl, dinv, B, ldb);
   return trans ? trsm_ltn(h->stream, n, m, L, ldl, dinv, B, ldb) : trsm_lln(h->stream, n, m, L, ldl, dinv, B, ldb);
 }
 
@@ -325,6 +360,7 @@ int gpx_destroy(gpx_handle* h) {
   if (h->red) (void)hipFree(h->red);
   if (h->info_dev) (void)hipFree(h->info_dev);
   if (h->gemm_ws) (void)hipFree(h->gemm_ws);
+  if (h->trsv_ws) (void)hipFree(h->trsv_ws);
   if (h->host_pin) (void)hipHostFree(h->host_pin);
   gpx_gemm_set_workspace(nullptr, 0);   // the thread's split-K workspace pointed into this handle
   delete h;
@@ -372,7 +408,6 @@ int gpx_gram_dtheta(gpx_handle* h, int kind, const double* X1, int n1, int ldx1,
   if (n1 <= 0 || n2 <= 0) return 0;
   GPX_REQUIRE(X1 && K && dsigma && dbeta, "gram_dtheta: null pointer");
   GPX_REQUIRE(ld >= n2 && ldx1 >= d && ldx2 >= d, "gram_dtheta: bad leading dimension");
-  GPX_REQUIRE(n1 <= 65535, "gram_dtheta: n1 too large for the dense dtheta path");
   GPX_REQUIRE(nbeta == 1 || plane >= (size_t)(n1 - 1) * ld + n2, "gram_dtheta: plane stride too small");
   DeviceGuard dg(h);
   return gpx_gram_dtheta_launch(h->stream, X1, n1, ldx1, X2, n2, ldx2, d, nbeta, sigma, b, K, dsigma,
@@ -694,10 +729,11 @@ int gpx_gpr_lml_grad(gpx_handle* h, int kind, const double* X, int n, int ldx, i
   GPX_HIP(hipMemsetAsync(rhs, 0, 2L * n * sizeof(double), s));
   GPX_HIP(hipMemcpy2DAsync(rhs, ldv * sizeof(double), y, sizeof(double), sizeof(double), n,
                            hipMemcpyDeviceToDevice, s));
-  GPX_TRY(solve_lower(h, 0, n, 1, Ky, ldk, dinv, rhs, ldv));
+  double* tws = trsv_prepare(h, n, Ky, ldk, dinv);   // block inverses once, both solves use them
+  GPX_TRY(trsv_prepared(h, tws, 0, n, Ky, ldk, dinv, rhs, ldv));
   GPX_HIP(hipMemcpy2DAsync(a_vec, sizeof(double), rhs, ldv * sizeof(double), sizeof(double), n,
                            hipMemcpyDeviceToDevice, s));
-  GPX_TRY(solve_lower(h, 1, n, 1, Ky, ldk, dinv, rhs, ldv));
+  GPX_TRY(trsv_prepared(h, tws, 1, n, Ky, ldk, dinv, rhs, ldv));
   GPX_HIP(hipMemcpy2DAsync(al_vec, sizeof(double), rhs, ldv * sizeof(double), sizeof(double), n,
                            hipMemcpyDeviceToDevice, s));
   GPX_TRY(gpx_dot_launch(s, n, a_vec, a_vec, h->red, sc));        // a . a
@@ -744,7 +780,7 @@ int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, in
   BetaArg b;
   int nbeta;
   GPX_TRY(fill_beta(kind, d, beta_host, b, nbeta));
-  GPX_REQUIRE(n > 0 && m > 0 && X && Xs && y && vec && mean && ldx >= d && ldxs >= d, "gpr_predict: bad arguments");
+  GPX_REQUIRE(n > 0 && m > 0 && X && Xs && vec && mean && ldx >= d && ldxs >= d, "gpr_predict: bad arguments");
   GPX_TRY(check_mat("gpr_predict: L", L, ldl, n));
   GPX_TRY(check_mat("gpr_predict: V", V, ldv, m));
   GPX_REQUIRE(gpx_aligned16(vec) && dinv && gpx_aligned16(dinv), "gpr_predict: scratch must be 16-byte aligned");
@@ -755,12 +791,14 @@ int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, in
   // a = L^-1 y  (regression.py:37)
   double* rhs = vec;
   double* a_vec = vec + 2L * n;
-  GPX_HIP(hipMemsetAsync(rhs, 0, 2L * n * sizeof(double), s));
-  GPX_HIP(hipMemcpy2DAsync(rhs, 2 * sizeof(double), y, sizeof(double), sizeof(double), n,
-                           hipMemcpyDeviceToDevice, s));
-  GPX_TRY(solve_lower(h, 0, n, 1, L, ldl, dinv, rhs, 2));
-  GPX_HIP(hipMemcpy2DAsync(a_vec, sizeof(double), rhs, 2 * sizeof(double), sizeof(double), n,
-                           hipMemcpyDeviceToDevice, s));
+  if (y != nullptr) {   // y == NULL: vec[2n, 3n) still holds a = L^-1 y from gpx_gpr_lml_grad on the same vec
+    GPX_HIP(hipMemsetAsync(rhs, 0, 2L * n * sizeof(double), s));
+    GPX_HIP(hipMemcpy2DAsync(rhs, 2 * sizeof(double), y, sizeof(double), sizeof(double), n,
+                             hipMemcpyDeviceToDevice, s));
+    GPX_TRY(solve_lower(h, 0, n, 1, L, ldl, dinv, rhs, 2));
+    GPX_HIP(hipMemcpy2DAsync(a_vec, sizeof(double), rhs, 2 * sizeof(double), sizeof(double), n,
+                             hipMemcpyDeviceToDevice, s));
+  }
   // k* = K(Xtr, Xs) (regression.py:33), V = L^-1 k* (regression.py:38)
   GPX_TRY(gpx_gram_launch(s, X, n, ldx, Xs, m, ldxs, d, sigma, b, 0.0, V, ldv, GPX_FULL));
   GPX_TRY(solve_lower(h, 0, n, m, L, ldl, dinv, V, ldv));

@@ -16,6 +16,10 @@ struct gpx_handle {
   int* info_dev = nullptr;    // device int
   double* host_pin = nullptr; // pinned host staging for scalars, HOST_PIN doubles
   double* gemm_ws = nullptr;  // device, GPX_GEMM_WS_ELEMS doubles: partial tiles of the GEMM's split-K tail
+  // device, grown on demand: block inverses + work vectors of the single-right-hand-side solves at n >= 8192
+  // (gpx_trsv_blockinv_elems(n) doubles: 0.5 GB at n = 65536); freed by gpx_destroy
+  double* trsv_ws = nullptr;
+  size_t trsv_ws_elems = 0;
 };
 
 constexpr size_t GPX_RED_ELEMS = 1u << 23;  // 64 MiB of reduction partials
@@ -81,6 +85,11 @@ struct GemmDesc {
   // size are independent, and at the small sizes a launch per block is launch-latency bound.
   int batch = 1;
   long stride_a = 0, stride_b = 0, stride_d = 0;   // (Cin, when given, moves with D)
+  // two-level batch (batch_inner > 0): member z = zo * batch_inner + zi starts zi * stride_x + zo * stride2_x after
+  // member 0 -- the diagonal sub-blocks (zi) of several separately stored blocks (zo): the block inverses of the
+  // single-right-hand-side solves (trsv.hip)
+  int batch_inner = 0;
+  long stride2_a = 0, stride2_b = 0, stride2_d = 0;
   // Column-block output (the grouped trailing update of the sharded Cholesky, gpx_gemm_colblocks): the N columns
   // are cb_nb-wide blocks, block c of which lives in its own slab of leading dimension cb_nb -- element (row, col)
   // at D[cb_off[c] + (cb_rowbase + row) * cb_nb + col - c * cb_nb] -- and exists only from row cb_row0[c] -
@@ -122,6 +131,16 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int n
 // trsv.hip: x <- L^-1 x (trans 0) / L^-T x (trans 1) for one strided vector
 int gpx_trsv_launch(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv, double* x,
                     long incx, double* red, size_t red_elems);
+// The same solves through explicit inverses of the 1024 x 1024 diagonal blocks (64 chain steps of two streaming
+// launches at n = 65536 instead of 511 dependent launches).  ws: gpx_trsv_blockinv_elems(n) doubles; prepare() fills
+// it from L and dinv (7 launches, n * 1024^2 / 3 flops), solve() may then be called any number of times for the
+// same factor.  Worth it from n = GPX_TRSV_BLOCKINV_MIN on.
+constexpr int GPX_TRSV_BLOCK = 1024;
+constexpr int GPX_TRSV_BLOCKINV_MIN = 8192;
+size_t gpx_trsv_blockinv_elems(int n);
+int gpx_trsv_blockinv_prepare(hipStream_t s, int n, const double* L, long ldl, const double* dinv, double* ws);
+int gpx_trsv_blockinv_solve(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv,
+                            double* ws, double* x, long incx, double* red, size_t red_elems);
 // y = W x (trans = 0) or W^T x (trans = 1) for a lower-triangular W (only j <= i read); y must not alias x
 int gpx_trmv_lower_launch(hipStream_t s, int trans, int n, const double* W, long ldw, const double* x, double* y,
                           double* red, size_t red_elems);

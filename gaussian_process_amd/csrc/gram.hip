@@ -517,8 +517,18 @@ int gpx_gram_dtheta_launch(hipStream_t s, const double* X1, int n1, long ldx1, c
   a.X1 = X1; a.ldx1 = ldx1; a.n1 = n1; a.X2 = X2; a.ldx2 = ldx2; a.n2 = n2;
   a.d = d; a.nbeta = nbeta; a.sigma = sigma; a.K = K; a.dsigma = dsigma; a.dbeta = dbeta;
   a.ld = ld; a.plane = plane; a.beta = hb;
-  dim3 grid((n2 + 255) / 256, n1);
-  hipLaunchKernelGGL(gram_dtheta_kernel, grid, dim3(256), 0, s, a);
+  // grid.y carries the row: at most 65535 per launch, so a tall matrix goes out in row chunks
+  constexpr int ROWS_PER_LAUNCH = 32768;
+  for (int r0 = 0; r0 < n1; r0 += ROWS_PER_LAUNCH) {
+    DthetaArgs c = a;
+    c.n1 = n1 - r0 < ROWS_PER_LAUNCH ? n1 - r0 : ROWS_PER_LAUNCH;
+    c.X1 = X1 + (long)r0 * ldx1;
+    c.K = K + (long)r0 * ld;
+    c.dsigma = dsigma + (long)r0 * ld;
+    c.dbeta = dbeta + (long)r0 * ld;
+    dim3 grid((n2 + 255) / 256, c.n1);
+    hipLaunchKernelGGL(gram_dtheta_kernel, grid, dim3(256), 0, s, c);
+  }
   GPX_HIP(hipGetLastError());
   return 0;
 }

@@ -195,11 +195,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void trsv_leaf_bwd_kernel(int n, cons
 }
 
 // ---- x2 -= A x1, A n2 x n1 row-major (n1 a multiple of 128): 16 rows per workgroup -------------
-__global__ __launch_bounds__(256) void trsv_gemvn_kernel(int n2, int n1, const double* A, long lda,
-                                                         const double* x1, double* x2, long incx) {
-  __shared__ double xs[XCHUNK];
+__device__ __forceinline__ void gemvn_body(double* xs, int blk, int n2, int n1, const double* A, long lda,
+                                           const double* x1, double* x2, long incx) {
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, g = lane >> 4, l16 = lane & 15;
-  const int r = blockIdx.x * 16 + wid * 4 + g;
+  const int r = blk * 16 + wid * 4 + g;
   const double* row = A + (long)min(r, n2 - 1) * lda;
   double acc = 0.0;
   for (int c0 = 0; c0 < n1; c0 += XCHUNK) {
@@ -219,6 +218,12 @@ __global__ __launch_bounds__(256) void trsv_gemvn_kernel(int n2, int n1, const d
   }
   acc = group16_sum(acc);
   if (l16 == 0 && r < n2) x2[(long)r * incx] -= acc;
+}
+
+__global__ __launch_bounds__(256) void trsv_gemvn_kernel(int n2, int n1, const double* A, long lda,
+                                                         const double* x1, double* x2, long incx) {
+  __shared__ double xs[XCHUNK];
+  gemvn_body(xs, blockIdx.x, n2, n1, A, lda, x1, x2, incx);
 }
 
 // ---- x1 -= A^T x2 (A n2 x n1 row-major): column sums per row chunk, then a fixed-order final pass ----
@@ -341,11 +346,10 @@ int bwd(hipStream_t s, int n, const double* L, long ldl, const double* dinv, dou
 // select, so NaN / Inf there are harmless.
 
 // y = W x: 16 rows per workgroup, 16 lanes per row; the long rows (bottom of the matrix) are dispatched first.
-__global__ __launch_bounds__(256) void trmv_lower_n_kernel(int n, const double* W, long ldw, const double* x,
-                                                           double* y) {
-  __shared__ double xs[XCHUNK];
+__device__ __forceinline__ void trmv_n_body(double* xs, int blk, int nblk, int n, const double* W, long ldw,
+                                            const double* x, double* y) {
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, g = lane >> 4, l16 = lane & 15;
-  const int r0 = (int)(gridDim.x - 1 - blockIdx.x) * 16;
+  const int r0 = (nblk - 1 - blk) * 16;
   const int r = r0 + wid * 4 + g;
   const double* row = W + (long)min(r, n - 1) * ldw;
   const int d0 = (r0 / NB) * NB;   // first column of the diagonal 128-segment, the same for the 16 rows
@@ -376,6 +380,12 @@ __global__ __launch_bounds__(256) void trmv_lower_n_kernel(int n, const double* 
   }
   acc = group16_sum(acc);
   if (l16 == 0 && r < n) y[r] = acc;
+}
+
+__global__ __launch_bounds__(256) void trmv_lower_n_kernel(int n, const double* W, long ldw, const double* x,
+                                                           double* y) {
+  __shared__ double xs[XCHUNK];
+  trmv_n_body(xs, (int)blockIdx.x, (int)gridDim.x, n, W, ldw, x, y);
 }
 
 // y = W^T x: column sums per row chunk (as trsv_gemvt_partial_kernel), rows >= column only; chunks that lie
@@ -453,6 +463,239 @@ int gpx_trmv_lower_launch(hipStream_t s, int trans, int n, const double* W, long
                      x, rows, red);
   GPX_HIP(hipGetLastError());
   hipLaunchKernelGGL(trmv_lower_t_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, npad, nchunks, rows, red, y);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same solves through EXPLICIT INVERSES of the 1024 x 1024 diagonal blocks.
+//
+// The recursion above is a chain of 2 n / 256 - 1 dependent launches (511 at n = 65536), each with 7-9 us of
+// fixed cost: 6.3 / 6.9 ms for a solve that streams 17 GB (2.7 / 2.5 TB/s).  With W_t = L_tt^-1 for the diagonal
+// blocks of order B = 1024 a solve is n / B steps of TWO streaming launches each,
+//     forward:   x_t = W_t r_t,      r_{s > t} -= L[s, t] x_t            (row-major GEMV over all CUs)
+//     backward:  x_t = W_t^T r_t,    r_{s < t} -= L[t, s]^T x_t          (column sums of a 1024-row block:
+//                                                                         one workgroup per strip of columns, no partials)
+// i.e. 128 launches: a small one that completes the next block's right-hand side, and one that forms x_next
+// (64 workgroups) TOGETHER with the update of the rest, so the latency-bound triangular multiply hides under the
+// streaming part.  The inverses are formed level by level from the 128-block inverses in dinv, all blocks
+// of a level in two batched MFMA GEMM launches (as trtri_levels in gpx_api.hip, here on copies of the diagonal
+// blocks: L itself is not touched): n B^2 / 3 flops, 7 launches -- 0.5 ms at n = 65536.  The ragged tail
+// (n mod 1024 rows) goes through the recursion.  Fixed association order everywhere: bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int BB = GPX_TRSV_BLOCK;
+
+// ws block t (ld BB) <- lower 128-blocks of L's diagonal block t, its diagonal 128-blocks <- dinv
+__global__ __launch_bounds__(256) void binv_init_kernel(const double* L, long ldl, const double* dinv, double* ws) {
+  const int t = blockIdx.z;
+  const int bi = blockIdx.y / (BB / NB), bj = blockIdx.y % (BB / NB);
+  if (bj > bi) return;
+  const int e = blockIdx.x * 256 + threadIdx.x;   // 0 .. 128 * 64 - 1: (row, column pair)
+  const int i = e >> 6, j = (e & 63) * 2;
+  double* dst = ws + (size_t)t * BB * BB + (size_t)(bi * NB + i) * BB + bj * NB + j;
+  v2d v;
+  if (bi == bj) v = *reinterpret_cast<const v2d*>(dinv + ((size_t)t * (BB / NB) + bi) * NB * NB + i * NB + j);
+  else v = *reinterpret_cast<const v2d*>(L + ((long)t * BB + bi * NB + i) * ldl + (long)t * BB + bj * NB + j);
+  *reinterpret_cast<v2d*>(dst) = v;
+}
+
+// dst[i] = src[i * inc] (gather) or dst[i * inc] = src[i] (scatter)
+__global__ void vec_copy_kernel(int n, const double* src, long sinc, double* dst, long dinc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[(long)i * dinc] = src[(long)i * sinc];
+}
+
+// Column sums of a block of at most XCHUNK rows, one workgroup per strip of SW columns, complete in the workgroup:
+//   mode 0:  y[c] -= sum_r A[r][c] v[r]                 (r < rows)
+//   mode 1:  y[c]  = sum_{r >= c} A[r][c] v[r]          (A lower triangular rows x rows, cols == rows)
+// SW = 128: a wave reads 1 KiB of one row per load, 4 row lanes; SW = 64: 512 bytes per row, 8 row lanes (twice as
+// many workgroups for the narrow blocks near the top of the matrix); SW = 16: one 128-byte line per row, 32 row
+// lanes -- 64 workgroups for a single 1024 x 1024 block (the small launch on the chain).  8 rows in flight per thread.
+template <int SW>
+__device__ __forceinline__ void strip_body(double* vs, v2d* red, int blk, int rows, int cols, const double* A, long lda,
+                                           const double* v, double* y, int mode) {
+  constexpr int CPW = SW / 2, RL = 256 / CPW;   // column pairs per strip, row lanes
+  const int t = threadIdx.x, cp = t % CPW, rl = t / CPW;
+  const int c0 = blk * SW, c = c0 + 2 * cp;
+  for (int i = t; i < rows; i += 256) vs[i] = v[i];
+  __syncthreads();
+  const int cc = min(c, cols - 2);            // cols is a multiple of SW on every path; the clamp keeps loads in range
+  const double* a = A + cc;
+  v2d acc = {0.0, 0.0};
+  if (!mode) {
+#pragma unroll 8
+    for (int r = rl; r < rows; r += RL) {
+      const v2d q = *reinterpret_cast<const v2d*>(a + (long)r * lda);
+      const double x = vs[r];
+      acc.x = fma(q.x, x, acc.x);
+      acc.y = fma(q.y, x, acc.y);
+    }
+  } else {
+    const int rbeg = (c0 / RL) * RL;          // lower: rows above the strip's first column contribute nothing
+#pragma unroll 8
+    for (int r = rbeg + rl; r < rows; r += RL) {
+      const v2d q = *reinterpret_cast<const v2d*>(a + (long)r * lda);
+      const double x = vs[r];
+      acc.x = fma(c <= r ? q.x : 0.0, x, acc.x);
+      acc.y = fma(c + 1 <= r ? q.y : 0.0, x, acc.y);
+    }
+  }
+  red[rl * CPW + cp] = acc;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    v2d sum = red[cp];
+#pragma unroll
+    for (int q = 1; q < RL; ++q) sum += red[q * CPW + cp];
+    if (mode) {
+      y[c] = sum.x;
+      y[c + 1] = sum.y;
+    } else {
+      y[c] -= sum.x;
+      y[c + 1] -= sum.y;
+    }
+  }
+}
+
+template <int SW>
+__global__ __launch_bounds__(256) void gemvt_strip_kernel(int rows, int cols, const double* A, long lda, const double* v,
+                                                           double* y, int mode) {
+  __shared__ double vs[XCHUNK];
+  __shared__ v2d red[256];
+  strip_body<SW>(vs, red, (int)blockIdx.x, rows, cols, A, lda, v, y, mode);
+}
+
+// One chain step of the forward solve in ONE launch: workgroups [0, nb_tri) form x_next = W_next r_next (the block
+// whose right-hand side the previous, small launch has just completed), the others subtract L[rows below, cur] x_cur
+// from the rest of the right-hand side -- the triangular multiply (latency-bound, 64 workgroups) hides under the
+// streaming update instead of standing between two launches.
+__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(int nb_tri, const double* Wn, const double* r_next, double* sol_next,
+                                                            int n2, const double* A, long lda, const double* sol_cur,
+                                                            double* r_rest) {
+  __shared__ double xs[XCHUNK];
+  const int b = blockIdx.x;
+  if (b < nb_tri) trmv_n_body(xs, b, nb_tri, BB, Wn, (long)BB, r_next, sol_next);
+  else gemvn_body(xs, b - nb_tri, n2, BB, A, lda, sol_cur, r_rest, 1L);
+}
+
+// The mirror image for the backward solve: workgroups [0, nb_tri) form x_prev = W_prev^T r_prev, the others subtract
+// L[cur, columns left of prev]^T x_cur from the rest.
+template <int SW>
+__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(int nb_tri, const double* Wp, const double* r_prev, double* sol_prev,
+                                                            int cols_rest, const double* A, long lda, const double* sol_cur,
+                                                            double* r_rest) {
+  __shared__ double vs[XCHUNK];
+  __shared__ v2d red[256];
+  const int b = blockIdx.x;
+  if (b < nb_tri) strip_body<SW>(vs, red, b, BB, BB, Wp, (long)BB, r_prev, sol_prev, 1);
+  else strip_body<SW>(vs, red, b - nb_tri, BB, cols_rest, A, lda, sol_cur, r_rest, 0);
+}
+
+}  // namespace
+
+size_t gpx_trsv_blockinv_elems(int n) {
+  if (n < BB) return 0;
+  const size_t npad = ((size_t)n + 63) / 64 * 64;
+  return (size_t)(n / BB) * BB * BB + 2 * npad;
+}
+
+int gpx_trsv_blockinv_prepare(hipStream_t s, int n, const double* L, long ldl, const double* dinv, double* ws) {
+  const int T = n / BB;   // full blocks only
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(binv_init_kernel, dim3(NB * 64 / 256, (BB / NB) * (BB / NB), T), dim3(256), 0, s, L, ldl, dinv, ws);
+  GPX_HIP(hipGetLastError());
+  // W21 = -W22 (L21 W11) for all 2 sz-blocks of a level (inner batch) of all T diagonal blocks (outer batch); T^T is
+  // kept in the block that mirrors L21 above the diagonal (see trtri_rec in gpx_api.hip)
+  for (int sz = NB; sz < BB; sz *= 2) {
+    const int inner = BB / (2 * sz);
+    const long si = 2L * sz * (BB + 1), so = (long)BB * BB;
+    double* L21 = ws + (long)sz * BB;
+    double* L22 = L21 + sz;
+    double* Tt = ws + sz;
+    GemmDesc g1;
+    g1.A = ws; g1.lda = BB; g1.a_lay = GPX_LAY_RC; g1.a_tri = 1;
+    g1.B = L21; g1.ldb = BB; g1.b_lay = GPX_LAY_KC; g1.b_tri = 0;
+    g1.Cin = nullptr; g1.ldcin = 0; g1.D = Tt; g1.ldd = BB;
+    g1.M = g1.N = g1.K = sz; g1.alpha = 1.0; g1.beta = 0.0;
+    g1.c_lower = 0; g1.diag_add = 0.0; g1.inplace = 0;
+    g1.batch = inner * T; g1.batch_inner = inner;
+    g1.stride_a = g1.stride_b = g1.stride_d = si;
+    g1.stride2_a = g1.stride2_b = g1.stride2_d = so;
+    int rc = gpx_gemm_launch(s, g1);
+    if (rc != 0) return rc;
+    GemmDesc g2 = g1;
+    g2.A = L22; g2.a_lay = GPX_LAY_KC;
+    g2.B = Tt; g2.b_lay = GPX_LAY_KC;
+    g2.D = L21; g2.alpha = -1.0;
+    rc = gpx_gemm_launch(s, g2);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+int gpx_trsv_blockinv_solve(hipStream_t s, int trans, int n, const double* L, long ldl, const double* dinv,
+                            double* ws, double* x, long incx, double* red, size_t red_elems) {
+  const int T = n / BB, nt = n - T * BB;   // full blocks, rows of the ragged tail
+  const size_t npad = ((size_t)n + 63) / 64 * 64;
+  double* r = ws + (size_t)T * BB * BB;     // running right-hand side
+  double* sol = r + npad;                   // solution
+  hipLaunchKernelGGL(vec_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, x, incx, r, 1L);
+  const double* dinv_tail = dinv + (size_t)T * (BB / NB) * NB * NB;
+  auto Wt = [&](int t) { return ws + (size_t)t * BB * BB; };
+  auto Lblk = [&](int bi, int bj) { return L + (long)bi * BB * ldl + (long)bj * BB; };
+  if (!trans) {
+    if (T > 0) hipLaunchKernelGGL(trmv_lower_n_kernel, dim3(BB / 16), dim3(256), 0, s, BB, Wt(0), (long)BB, r, sol);
+    for (int t = 0; t < T; ++t) {
+      double* sol_t = sol + (long)t * BB;
+      if (t + 1 < T) {
+        // small launch: the next block's right-hand side; then x_next together with the update of everything below it
+        hipLaunchKernelGGL(trsv_gemvn_kernel, dim3(BB / 16), dim3(256), 0, s, BB, BB, Lblk(t + 1, t), ldl, sol_t,
+                           r + (long)(t + 1) * BB, 1L);
+        const int n2 = n - (t + 2) * BB;
+        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(BB / 16 + (n2 + 15) / 16), dim3(256), 0, s, BB / 16, Wt(t + 1),
+                           r + (long)(t + 1) * BB, sol + (long)(t + 1) * BB, n2, Lblk(t + 2, t), ldl, sol_t,
+                           r + (long)(t + 2) * BB);
+      } else if (nt > 0) {
+        const int rc = launch_gemvn(s, nt, BB, Lblk(T, t), ldl, sol_t, r + (long)T * BB, 1L);
+        if (rc != 0) return rc;
+      }
+    }
+    if (nt > 0) {
+      const int rc = fwd(s, nt, L + (long)T * BB * (ldl + 1), ldl, dinv_tail, r + (long)T * BB, 1L);
+      if (rc != 0) return rc;
+      hipLaunchKernelGGL(vec_copy_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, nt, r + (long)T * BB, 1L, sol + (long)T * BB, 1L);
+    }
+  } else {
+    if (nt > 0) {
+      const int rc = bwd(s, nt, L + (long)T * BB * (ldl + 1), ldl, dinv_tail, r + (long)T * BB, 1L, red, red_elems);
+      if (rc != 0) return rc;
+      hipLaunchKernelGGL(vec_copy_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, nt, r + (long)T * BB, 1L, sol + (long)T * BB, 1L);
+      // r[0 : T B] -= L[tail rows, 0 : T B]^T x_tail
+      if (T > 0)
+        hipLaunchKernelGGL((gemvt_strip_kernel<64>), dim3(T * BB / 64), dim3(256), 0, s, nt, T * BB, L + (long)T * BB * ldl, ldl,
+                           sol + (long)T * BB, r, 0);
+    }
+    if (T > 0)
+      hipLaunchKernelGGL((gemvt_strip_kernel<16>), dim3(BB / 16), dim3(256), 0, s, BB, BB, Wt(T - 1), (long)BB,
+                         r + (long)(T - 1) * BB, sol + (long)(T - 1) * BB, 1);
+    for (int t = T - 1; t > 0; --t) {
+      double* sol_t = sol + (long)t * BB;
+      // small launch: the previous block's right-hand side; then x_prev together with the update of everything left of it
+      // (16-column strips: 64 workgroups of 128 KiB each; with 64-column strips this launch took 16 us on 16 workgroups)
+      hipLaunchKernelGGL((gemvt_strip_kernel<16>), dim3(BB / 16), dim3(256), 0, s, BB, BB, Lblk(t, t - 1), ldl, sol_t,
+                         r + (long)(t - 1) * BB, 0);
+      const int cols_rest = (t - 1) * BB;
+      // wide strips once the update alone has enough workgroups for the chip, narrow ones near the top of the matrix
+      if (cols_rest / 128 >= 256)
+        hipLaunchKernelGGL((trsv_bwd_step_kernel<128>), dim3(BB / 128 + cols_rest / 128), dim3(256), 0, s, BB / 128, Wt(t - 1),
+                           r + (long)(t - 1) * BB, sol + (long)(t - 1) * BB, cols_rest, Lblk(t, 0), ldl, sol_t, r);
+      else
+        hipLaunchKernelGGL((trsv_bwd_step_kernel<64>), dim3(BB / 64 + cols_rest / 64), dim3(256), 0, s, BB / 64, Wt(t - 1),
+                           r + (long)(t - 1) * BB, sol + (long)(t - 1) * BB, cols_rest, Lblk(t, 0), ldl, sol_t, r);
+    }
+  }
+  hipLaunchKernelGGL(vec_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, sol, 1L, x, incx);
   GPX_HIP(hipGetLastError());
   return 0;
 }

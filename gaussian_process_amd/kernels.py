@@ -14,6 +14,7 @@ Deliberate differences:
     (kernels.py:34-36); the two agree to ~2e-15 and the diagonal is exactly ``sigma``.
 """
 from collections import namedtuple
+from collections.abc import Mapping
 
 import numpy as np
 from sklearn.base import BaseEstimator
@@ -22,6 +23,39 @@ from . import _lib
 from .device import on_device, ptr, runtime
 
 KernelValue = namedtuple("KernelValue", ["K", "dtheta"])
+
+
+class LazyDtheta(Mapping):
+    """``KernelValue.dtheta`` of the device kernels: the mapping {'sigma': dK/dsigma, 'beta': dK/dbeta} of
+    kernels.py:45,87 (same keys, same insertion order, same dense arrays), but the derivative planes -- for ARD a
+    (d, n1, n2) stack, kernels.py:80 -- are built on the device and downloaded only when an entry is first READ.
+    Callers that want K alone (the reference computes and throws the planes away at regression.py:32-33,41 and
+    expectation_propagation.py:19,111) never pay for them; the estimators' gradients contract them on the device
+    without materialising them at all (gpx_grad_trace)."""
+    _KEYS = ("sigma", "beta")
+
+    def __init__(self, build):
+        self._build, self._planes = build, None
+
+    def _get(self):
+        if self._planes is None:
+            self._planes = self._build()
+            self._build = None
+        return self._planes
+
+    def __getitem__(self, key):
+        if key not in self._KEYS:
+            raise KeyError(key)
+        return self._get()[key]
+
+    def __iter__(self):
+        return iter(self._KEYS)
+
+    def __len__(self):
+        return len(self._KEYS)
+
+    def __repr__(self):
+        return "LazyDtheta(%s)" % ("materialised" if self._planes is not None else "pending")
 
 _LOWER_BOUND = 1e-5
 
@@ -48,6 +82,12 @@ def _restore_nan(arr, bad1, bad2):
     if bad2 is not None:
         arr[..., :, bad2] = np.nan
     return arr
+
+
+def clone_params(kernel):
+    """A copy of a kernel object with its current parameter values (arrays copied)."""
+    import copy
+    return copy.deepcopy(kernel)
 
 
 class _StationaryKernel(BaseEstimator):
@@ -128,10 +168,16 @@ class _StationaryKernel(BaseEstimator):
             nb = len(self._beta_vector(d1))
             dbeta = np.zeros(m) if self.kind == "rbf" else np.zeros((nb, m))
             return KernelValue(float(self.sigma) * np.ones(m), {"sigma": np.ones(m), "beta": dbeta})
-        K, dsig, dbeta = self._evaluate(X1, X2)
-        if self.kind == "rbf":
-            dbeta = dbeta[0]
-        return KernelValue(K, {"sigma": dsig, "beta": dbeta})
+        # K now; the derivative planes when (and if) somebody reads dtheta.  The parameters are frozen at call
+        # time: a later set_params must not change what this KernelValue's dtheta means.
+        frozen = clone_params(self)
+        K = frozen._evaluate(X1, X2, want_dtheta=False)[0]
+
+        def build():
+            _, dsig, dbeta = frozen._evaluate(X1, X2)
+            return {"sigma": dsig, "beta": dbeta[0] if frozen.kind == "rbf" else dbeta}
+
+        return KernelValue(K, LazyDtheta(build))
 
 
 class RBF(_StationaryKernel):

@@ -174,7 +174,8 @@ class GaussianProcessRegression(RegressorMixin, BayesEstimator):
         if st["has_factor"]:
             rc = rt.lib.gpx_gpr_predict(
                 rt.h, key[0], ptr(dv["X"]), self.n, dv["X"].shape[1], self.dim, key[1], beta_p, key[3],
-                ptr(dv["y"]), ptr(dv["Ky"]), dv["Ky"].shape[1], ptr(dv["dinv"]), ptr(dXs), m, dXs.shape[1],
+                None,      # a = L^-1 y is still in vec[2n, 3n) from the LML evaluation that left this factor
+                ptr(dv["Ky"]), dv["Ky"].shape[1], ptr(dv["dinv"]), ptr(dXs), m, dXs.shape[1],
                 ptr(V), V.shape[1], ptr(dv["vec"]), ptr(mean), ptr(cov) if full_cov else None,
                 cov.shape[1] if full_cov else 0, None if full_cov else ptr(var), 1 if full_cov else 0)
             _lib.check(rc, "gpx_gpr_predict")

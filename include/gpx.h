@@ -225,7 +225,9 @@ int gpx_gpr_grad_from_factor(gpx_handle* h, int kind, const double* X, int n, in
                              const double* alpha, double* grad_host);
 /* regression.py:31-44 given the factor L (lower) of Ky and its dinv:
  *   V (n x ldv >= m) scratch, mean (m), cov (m x ldc) = K(Xs,Xs) - V^T V + noise I (full matrix,
- *   or only its lower triangle + mirrored when full_cov=1; full_cov=0 fills only var (m)). */
+ *   or only its lower triangle + mirrored when full_cov=1; full_cov=0 fills only var (m)).
+ *   vec: 3*n doubles.  y == NULL: vec[2n, 3n) already holds a = L^-1 y -- what gpx_gpr_lml_grad leaves there when
+ *   given the same vec -- and the forward solve of regression.py:37 is not repeated. */
 int gpx_gpr_predict(gpx_handle* h, int kind, const double* X, int n, int ldx, int d, double sigma,
                     const double* beta_host, double noise, const double* y, const double* L,
                     int ldl, const double* dinv, const double* Xs, int m, int ldxs, double* V,

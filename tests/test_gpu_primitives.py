@@ -253,6 +253,42 @@ def test_gram_dtheta_matches_oracle(rt):
     assert kv.dtheta["beta"].shape == (70, 70)
     assert np.abs(kv.dtheta["beta"] - db).max() < 1e-13 * np.abs(db).max()
     assert list(kv.dtheta) == ["sigma", "beta"]
+    # the planes are built on first read, from the parameters the kernel had when it was CALLED
+    cov = ARD(sigma=1.3, beta=[0.2, 1.0, 2.5])
+    kv = cov(X1, X2)
+    assert "pending" in repr(kv.dtheta) and len(kv.dtheta) == 2 and set(kv.dtheta.keys()) == {"sigma", "beta"}
+    cov.set_params(beta=np.array([9.0, 9.0, 9.0]), sigma=5.0)
+    K, ds, db = O.ard_cov(X1, X2, 1.3, np.array([0.2, 1.0, 2.5]), want_grad=True)
+    assert relerr(kv.dtheta["beta"], db) < 1e-13 and "materialised" in repr(kv.dtheta)
+    assert relerr(dict(kv.dtheta.items())["sigma"], ds) < 1e-13
+    with pytest.raises(KeyError):
+        kv.dtheta["gamma"]
+
+
+@pytest.mark.parametrize("n", [8192, 9000, 10241])
+def test_single_rhs_solves_through_block_inverses(rt, n):
+    """From n = 8192 on a single-right-hand-side solve goes through explicit inverses of the 1024 x 1024 diagonal
+    blocks (trsv.hip: 2 streaming launches per block instead of a chain of 256-row leaves); the ragged tail
+    (n mod 1024 rows: 808, 1) goes through the recursion.  Against SciPy's solve_triangular on the same factor
+    (regression.py:37,50 and the second half of cho_solve behind :61), strided and contiguous vectors."""
+    rng = np.random.default_rng(n)
+    L = np.tril(rng.uniform(-1, 1, (n, n))) / np.sqrt(n)
+    L[np.arange(n), np.arange(n)] = rng.uniform(1.0, 2.0, n)
+    dL = up(rt, L)
+    ld = dL.shape[1]
+    dinv = rt.dinv(n)
+    ok(rt.lib.gpx_diag_inv(rt.h, n, P(dL), ld, P(dinv)))
+    b = rng.standard_normal(n)
+    for trans in (0, 1):
+        want = sla.solve_triangular(L, b, lower=True, trans="T" if trans else "N", check_finite=False)
+        for inc in (1, 2):
+            x = rt.torch.zeros((n, inc), dtype=rt.torch.float64, device=rt.dev)
+            x[:, 0].copy_(rt.torch.from_numpy(b))
+            ok(rt.lib.gpx_trsm(rt.h, trans, n, 1, P(dL), ld, P(dinv), P(x), inc))
+            got = rt.download(x[:, 0])
+            assert relerr(got, want) < 1e-12, (trans, inc)
+    # the factor itself is untouched (the block inverses are built on copies)
+    assert np.array_equal(down(rt, dL, n, n), L)
 
 
 # ----------------------------------------------------------------------------- Cholesky family
