@@ -32,7 +32,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int EPB = GPX_EP_BLOCK;   // sites per delayed block = columns of Sbuf / Tbuf
 constexpr int ROWS = 32;            // rows of the state per workgroup
-constexpr int THREADS = 256;        // 8 threads per row
+constexpr int THREADS = 256;        // 8 threads per row: the four waves that own the workgroup's rows
+constexpr int SITE_THREADS = THREADS + 64;   // ep_sites_kernel: a fifth wave for the serial moment matches
 static_assert(EPB <= THREADS && EPB % 16 == 0, "one delayed column per thread; 16-wide row chunks");
 
 struct SiteState {   // one parity of the ping-pong state
@@ -72,7 +73,12 @@ __device__ __forceinline__ double sym_lower(const double* Sigma, long ld, int r,
   return r >= c ? Sigma[(long)r * ld + c] : Sigma[(long)c * ld + r];
 }
 
-__global__ __launch_bounds__(THREADS) void ep_sites_kernel(int n, SiteGroup grp, const double* Sigma, long ld,
+// The serial part -- the m moment matches, ~1.7 us each of dependent divisions, sqrt and erfcx in one lane -- runs
+// on a FIFTH wave while the four row waves form the dots of their rows with the columns already there
+// (Sbuf[r, :t0] . w_p: the only pass over memory, independent of the moment matches); the two meet at one barrier
+// and the row waves finish with the O(m^2) recursion per row.  (Round 2 ran the moment matches on lanes of wave 0
+// with the other waves waiting at the barrier: 21 us per launch of 8 sites, 13.6 us of it the serial part.)
+__global__ __launch_bounds__(SITE_THREADS) void ep_sites_kernel(int n, SiteGroup grp, const double* Sigma, long ld,
                                                            double* Sbuf, double* Tbuf, double* coef,
                                                            const double* y, SiteState in, SiteState out) {
   __shared__ double rowS[MS][EPB];   // Sbuf[i_q, j], zero for j >= t0
@@ -88,8 +94,9 @@ __global__ __launch_bounds__(THREADS) void ep_sites_kernel(int n, SiteGroup grp,
   const int tpad = (t0 + 15) & ~15;
 
   // ---- phase 1: everything that depends only on the state before the launch ----
+  const bool row_wave = tid < THREADS;           // waves 0-3 own rows; wave 4 runs the moment matches
   const int rl = tid >> 3, sub = tid & 7;
-  const int r = blockIdx.x * ROWS + rl;
+  const int r = row_wave ? blockIdx.x * ROWS + rl : n;
   double base = 0.0, mu_r = 0.0, tau_r = 0.0, nu_r = 0.0;
   if (r < n) {
     if (sub < m) base = sym_lower(Sigma, ld, r, grp.idx[sub]);   // lane `sub`: column i_sub of Sigma_0 at row r
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(THREADS) void ep_sites_kernel(int n, SiteGroup grp,
       nu_r = in.nu[r];
     }
   }
-  for (int e = tid; e < MS * EPB; e += THREADS) {   // rows of the unused slots (q >= m) are zero
+  for (int e = tid; e < MS * EPB; e += SITE_THREADS) {   // rows of the unused slots (q >= m) are zero
     const int q = e / EPB, j = e - q * EPB;
     double v = 0.0, c = 0.0;
     if (q < m && j < t0) {
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(THREADS) void ep_sites_kernel(int n, SiteGroup grp,
     stv[tid][3] = y[i];
   }
   __syncthreads();
-  {   // G[q][p]: 4 threads per pair, 64 pairs
+  if (row_wave) {   // G[q][p]: 4 threads per pair, 64 pairs
     const int pair = tid >> 2, part = tid & 3;
     const int q = pair / MS, p2 = pair % MS;
     double acc = 0.0;
@@ -134,12 +141,32 @@ __global__ __launch_bounds__(THREADS) void ep_sites_kernel(int n, SiteGroup grp,
   __syncthreads();
 
   // ---- phase 2: the sites one after the other (scalars; repeated identically in every workgroup) ----
-  // Lanes 0 .. MS-1 of wave 0 all run the moment match of site p (same inputs, same result); lane q > p
+  // Lanes 0 .. MS-1 of the FIFTH wave all run the moment match of site p (same inputs, same result); lane q > p
   // then forms its own entry E[q][p] of the new column, so the m - p - 1 entries cost one step, not m.
   // Reciprocals are shared (1 / Sigma_ii, 1 / sqrt(dom), 1 / tau_cav, 1 / var_hat): 6 divisions per site
   // instead of 11 on the serial path; the results differ from the division-by-division form by rounding.
-  if (tid < MS) {
-    const int q = tid;
+  double dsum[MS];
+#pragma unroll
+  for (int p2 = 0; p2 < MS; ++p2) dsum[p2] = 0.0;
+  if (row_wave) {
+    // ---- phase 3a (row waves, concurrently with phase 2): dots of this workgroup's rows with the columns already there
+    if (r < n) {
+      const double* srow = Sbuf + (long)r * EPB;
+      for (int j = 2 * sub; j < tpad; j += 16) {
+        const v2d sv = *reinterpret_cast<const v2d*>(srow + j);
+#pragma unroll
+        for (int p2 = 0; p2 < MS; ++p2) dsum[p2] = fma(sv.y, wv[p2][j + 1], fma(sv.x, wv[p2][j], dsum[p2]));
+      }
+    }
+#pragma unroll
+    for (int p2 = 0; p2 < MS; ++p2) {
+      dsum[p2] = reduce8(dsum[p2]);
+      // lane 0 of the row collects site p2's base entry from lane p2
+      const double b = __shfl(base, (tid & 56) + p2, 64);
+      dsum[p2] += b;
+    }
+  } else if (tid - THREADS < MS) {
+    const int q = tid - THREADS;
 #pragma unroll 1
     for (int p2 = 0; p2 < m; ++p2) {
       double sii = S0[p2][p2] + Gm[p2][p2];
@@ -186,25 +213,7 @@ __global__ __launch_bounds__(THREADS) void ep_sites_kernel(int n, SiteGroup grp,
   }
   __syncthreads();
 
-  // ---- phase 3: this workgroup's rows of the m new columns ----
-  double dsum[MS];
-#pragma unroll
-  for (int p2 = 0; p2 < MS; ++p2) dsum[p2] = 0.0;
-  if (r < n) {
-    const double* srow = Sbuf + (long)r * EPB;
-    for (int j = 2 * sub; j < tpad; j += 16) {
-      const v2d sv = *reinterpret_cast<const v2d*>(srow + j);
-#pragma unroll
-      for (int p2 = 0; p2 < MS; ++p2) dsum[p2] = fma(sv.y, wv[p2][j + 1], fma(sv.x, wv[p2][j], dsum[p2]));
-    }
-  }
-#pragma unroll
-  for (int p2 = 0; p2 < MS; ++p2) {
-    dsum[p2] = reduce8(dsum[p2]);
-    // lane 0 of the row collects site p2's base entry from lane p2
-    const double b = __shfl(base, (tid & 56) + p2, 64);
-    dsum[p2] += b;
-  }
+  // ---- phase 3b: this workgroup's rows of the m new columns (needs coef / gamma / E of phase 2) ----
   if (r < n && sub == 0) {
     double sc[MS];
     double mu_new = mu_r, tau_new = tau_r, nu_new = nu_r;
@@ -319,7 +328,7 @@ int gpx_ep_sweep_launch(hipStream_t s, int n, double* Sigma, long ld, const doub
       grp.idx[grp.m++] = i;
     }
     for (int q = grp.m; q < MS; ++q) grp.idx[q] = grp.idx[0];
-    hipLaunchKernelGGL(ep_sites_kernel, dim3(grid), dim3(THREADS), 0, s, n, grp, Sigma, ld, Sbuf, Tbuf, coef, y,
+    hipLaunchKernelGGL(ep_sites_kernel, dim3(grid), dim3(SITE_THREADS), 0, s, n, grp, Sigma, ld, Sbuf, Tbuf, coef, y,
                        st[launches & 1], st[(launches + 1) & 1]);
     ++launches;
     k += grp.m;
