@@ -35,7 +35,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD spec; 256 CU x 4 S
 # Fabric-side traffic of ONE dominant launch (M=N=K=16384) is not measurable from inside this process (PMC
 # counters need rocprofv3): it is READ from the committed summary of the round's PMC passes over
 # tools/gemm_launch.py (tools/profile_r02.sh writes it), and the JSON line names that file.
-TRAFFIC_SUMMARIES = ["profiles/r02_gemm_launch_pmc.json", "profiles/r01_gemm_launch_pmc.json"]
+TRAFFIC_SUMMARIES = ["profiles/r03_gemm_launch_pmc.json", "profiles/r02_gemm_launch_pmc.json", "profiles/r01_gemm_launch_pmc.json"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 

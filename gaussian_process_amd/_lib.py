@@ -41,6 +41,7 @@ SIGNATURES = {
     "gpx_gemm_colblocks": (_i, [C.c_void_p, _i, _i, _i, _d, _dp, _i, _dp, _i, _d, _dp, _i, _i, _dp, _dp]),
     "gpx_trmv": (_i, [C.c_void_p, _i, _i, _dp, _i, _dp, _dp]),
     "gpx_trmm": (_i, [C.c_void_p, _i, _i, _i, _dp, _i, _dp, _i, _dp, _i]),
+    "gpx_trmm_right": (_i, [C.c_void_p, _i, _i, _dp, _i, _dp, _i, _dp, _i]),
     "gpx_gemv": (_i, [C.c_void_p, _i, _i, _i, _dp, _i, _dp, _dp]),
     "gpx_gemv_acc": (_i, [C.c_void_p, _i, _i, _i, _d, _dp, _i, _dp, _d, _dp]),
     "gpx_colsumsq_sub": (_i, [C.c_void_p, _i, _i, _dp, _i, _d, _dp]),

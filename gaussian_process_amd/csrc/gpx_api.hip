@@ -916,6 +916,21 @@ int gpx_trmm(gpx_handle* h, int trans, int n, int m, const double* L, int ldl, c
   return gpx_gemm_launch(h->stream, g);
 }
 
+int gpx_trmm_right(gpx_handle* h, int m, int n, const double* W, int ldw, const double* X, int ldx, double* Out,
+                   int ldo) {
+  GPX_REQUIRE(h != nullptr, "null handle");
+  if (n <= 0 || m <= 0) return 0;
+  GPX_TRY(check_mat("trmm_right: W", W, ldw, n));
+  GPX_TRY(check_mat("trmm_right: X", X, ldx, n));
+  GPX_TRY(check_mat("trmm_right: Out", Out, ldo, n));
+  GPX_REQUIRE(Out != X, "trmm_right: Out must not alias X");
+  DeviceGuard dg(h);
+  // Out = X W^T: op(A) = X (stored [i][k]: KC), op(B) = W^T stored as W [j][k] (KC), valid k <= j
+  GemmDesc g = mk(X, ldx, GPX_LAY_KC, W, ldw, GPX_LAY_KC, nullptr, 0, Out, ldo, m, n, n, 1.0, 0.0);
+  g.b_tri = 1;
+  return gpx_gemm_launch(h->stream, g);
+}
+
 int gpx_ep_sweep(gpx_handle* h, int n, double* Sigma, int ld, const double* y, double* tau, double* nu,
                  const int* order_host, int count, double* work) {
   GPX_REQUIRE(h != nullptr && y && tau && nu && work, "ep_sweep: null argument");

@@ -48,10 +48,14 @@ constexpr int EXP_TAB = 64;
 // NaNs of non-finite test points on the host (regression.py / kernels.py: _nan_rows).
 __device__ __forceinline__ double exp_neg_tab(double h, const double* tab) {
   h = __builtin_fmin(h, 800.0);
+  // (rint + cvt were also tried as a magic-number addition -- h * c + 1.5 * 2^52, the integer read from the low word:
+  // no change, 5.35 against 5.17 ms for the trace kernel within box noise; v_rndne_f64 / v_cvt_i32_f64 are not what
+  // limits these kernels.  PMC: the Gram kernel issues VALU instructions on 91 % of its SIMD cycles, the trace
+  // kernel on 71 % -- both are bound by their fp64 instruction COUNT, 34 resp. 56 per element at d = 8.)
   const double kf = rint(h * -9.23324826168936574e+01);            // -64 / ln 2
+  const int ki = (int)kf;
   double r = fma(kf, -1.0830417275428772e-02, -h);                 // r = -h - kf * ln2/64: hi part (32 trailing zero bits: kf * hi is exact)
   r = fma(kf, -7.420820373486988e-09, r);                          // lo part
-  const int ki = (int)kf;
   const double tj = tab[ki & (EXP_TAB - 1)];                       // sigma * 2^(j/64)
   double p = horner(8.3333333333333332e-03, r, 4.1666666666666664e-02);   // 1/5!, 1/4!
   p = horner(p, r, 1.6666666666666666e-01);                        // 1/3!
@@ -250,7 +254,6 @@ struct TraceArgs {
   // gpx_lauum_upper leaves beside W = L^-1 in one n x n buffer.  The matrix is symmetric, so the sums are
   // the same; only the tile tests are mirrored.
   int upper; const double* kdiag;
-  int mode;          // development switch GPX_TRACE_MODE: 0 = round-2 interior loop (two rows in flight per wave)
   double* partials;  // [nblocks][nacc]
   BetaArg sb;        // sqrt(beta_k / 2): the squared differences below are beta_k diff_k^2 / 2 (the host doubles the sums)
   double tab[EXP_TAB];  // 2^(j/64): K_ij / sigma = exp_neg_tab(sum_k beta_k diff_k^2 / 2)
@@ -539,8 +542,6 @@ int gpx_grad_trace_launch(hipStream_t s, const double* X, long ldx, int d, int n
                           const double* kdiag) {
   TraceArgs a;
   a.upper = kdiag != nullptr; a.kdiag = kdiag;
-  static const int mode = [] { const char* e = getenv("GPX_TRACE_MODE"); return e ? atoi(e) : 1; }();   // development switch
-  a.mode = mode;
   a.X = X; a.ldx = ldx; a.nr = nr; a.nc = nc; a.roff = roff; a.coff = coff; a.d = d; a.nbeta = nbeta;
   a.sigma = sigma; a.alpha = alpha; a.Kinv = Kinv; a.ldk = ldk; a.partials = red;
   for (int k = 0; k < GPX_MAXD; ++k) a.sb.b[k] = k < d ? sqrt(0.5 * hb.b[k]) : 0.0;

@@ -93,7 +93,8 @@ def main(args, rank, local_rank, world, cpu_baseline=None, traffic=None):
             stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / args.steps
     names = ["gram", "potrf", "solve_lml", "predict", "grad"]
     mem = gp.resident_bytes
-    vec = torch.tensor([wall] + [stages[k] for k in names] + [float(mem["matrix"]), float(mem["panels"])],
+    vec = torch.tensor([wall] + [stages[k] for k in names] + [float(mem["matrix"]), float(mem["panels"]),
+                                                              float(mem["tile_inverses"])],
                        dtype=torch.float64, device=rt.dev)
     dist.all_reduce(vec, op=dist.ReduceOp.MAX)
     vec = vec.cpu().numpy()
@@ -120,7 +121,7 @@ def main(args, rank, local_rank, world, cpu_baseline=None, traffic=None):
             "fit_predict_wall_s": round(ms / 1e3, 4),
             "fit_predict_without_gradient_s": round(sum(stages[k] for k in names[:4]) / 1e3, 4),
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
-            "resident_bytes_per_rank_max": {"matrix": int(vec[6]), "panels": int(vec[7]),
+            "resident_bytes_per_rank_max": {"matrix": int(vec[6]), "panels": int(vec[7]), "tile_inverses": int(vec[8]),
                                             "lower_triangle_over_world": int(mem["lower_over_world"])},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (potrf phase, whole job)",
                          "achieved": round(potrf_tflops, 3), "peak": FP64_MFMA_PEAK_TFLOPS * world,

@@ -110,6 +110,11 @@ class GpuOps:
         _lib.check(self.lib.gpx_trmm(self.h, trans, W.shape[0], B.shape[1], self._p(W), W.stride(0), self._p(B),
                                      B.stride(0), self._p(Out), Out.stride(0)), "gpx_trmm")
 
+    def trmm_right(self, X, W, Out):
+        """Out = X W^T, W lower triangular (the panel solve with a diagonal tile's explicit inverse)."""
+        _lib.check(self.lib.gpx_trmm_right(self.h, X.shape[0], W.shape[0], self._p(W), W.stride(0), self._p(X), X.stride(0),
+                                           self._p(Out), Out.stride(0)), "gpx_trmm_right")
+
     def logdet(self, L):
         out = C.c_double()
         _lib.check(self.lib.gpx_logdet(self.h, L.shape[0], self._p(L), L.stride(0), C.byref(out)), "gpx_logdet")
@@ -210,6 +215,9 @@ class DistributedGP:
         self.grad_block = grad_block or 4096
         if many_rhs:
             self.MANY_RHS = many_rhs
+        # Panel solve with the diagonal tile's explicit inverse (one triangular-aware MFMA product, written straight
+        # into the ring of pending panels) instead of the recursion over the tile's 128-blocks; development switch
+        self.panel_inverse = os.environ.get("GPX_DIST_PANEL_INV", "1") != "0" and hasattr(ops, "trmm_right")
         # development switch: one launch per tile column (round 2) instead of grouped trailing updates, for A/B runs
         self.group_updates = os.environ.get("GPX_DIST_GROUP", "1") != "0"
         # development switch: the round-2 placement of the diagonal-tile potrf (side stream) for A/B runs
@@ -391,6 +399,9 @@ class DistributedGP:
         self.resident_bytes = dict(matrix=8 * total,
                                    panels=8 * (self.RB.numel() + (0 if self.cb_is_rb else self.CB.numel()) + numel(self.rowstg)
                                                + numel(self.tsend) + numel(self.trecv) + numel(self.dstg)),
+                                   # explicit inverses of the owned diagonal tiles (panel solves, many-right-hand-side
+                                   # tile solves): 1 / T of the matrix, allocated as the factorisation reaches them
+                                   tile_inverses=8 * sum(g.tile_h(k) * max(32, ((g.tile_h(k) + 31) // 32) * 32) for k in diag),
                                    lower_over_world=8 * g.lower_elems() // self.world)
 
     def set_theta(self, kind, sigma, beta, noise):
@@ -502,6 +513,7 @@ class DistributedGP:
         has_panel = k < g.T - 1
         wk = g.tile_h(k)
         below = None
+        filed_rows = False
         if q == qk:
             slab, rows = self.slabs[k], self.slab_rows[k]
             mine = p == pk
@@ -521,13 +533,21 @@ class DistributedGP:
                     ops.side_join(token)
                 else:
                     ops.potrf_async(slab[:wk, :wk], self.dinv[k], self.info, k * nb)
+            Wkk = None
+            if has_panel and self.panel_inverse and mine:
+                # W_kk = L_kk^-1 right behind the tile's potrf (level-by-level trtri on a copy, kept for the
+                # many-right-hand-side tile solves of predict / grad): the panel solve below is then ONE product
+                Wkk = self._tile_inverse(k)
             if has_panel and self.cc:
                 # the broadcast down the process column leaves as soon as the tile is factored; the update of
                 # the rows below (next) runs under it
                 dst = self.dstg
                 if mine:
-                    dst[: nb * nb].view(nb, nb).copy_(slab[:nb])
-                    dst[nb * nb:].copy_(self.dinv[k])
+                    if self.panel_inverse:
+                        dst[: nb * nb].view(nb, nb).copy_(Wkk[:, :nb])
+                    else:
+                        dst[: nb * nb].view(nb, nb).copy_(slab[:nb])
+                        dst[nb * nb:].copy_(self.dinv[k])
                 h_diag = self._bcast(dst, self._grank(pk, qk), self.col_group, async_op=True)
             if not (mine and self.side_potrf):
                 self._apply(k, k, wk if mine else 0, rows)
@@ -537,9 +557,20 @@ class DistributedGP:
                     h_diag.wait()
                     if not mine:
                         Lkk, dk = dst[: nb * nb].view(nb, nb), dst[nb * nb:]
+                        Wkk = Lkk                     # (panel_inverse: the payload is the inverse)
                 below = slab[nb:rows] if mine else slab[:rows]
                 if below.shape[0] > 0:
-                    ops.trsm_right(below, Lkk, dk)
+                    if self.panel_inverse:
+                        # solved rows straight into ring slot k (free since panel k - G was applied everywhere one
+                        # step ago), then back into the slab, which keeps the factor and feeds the row broadcast
+                        I1 = g.first_at_or_after(k + 1, p, P)
+                        slot = k % self.G
+                        ring = self.RB[g.lrow(I1): g.lrow(I1) + below.shape[0], slot * nb:(slot + 1) * nb]
+                        ops.trmm_right(below, Wkk[:nb, :nb], ring)
+                        below.copy_(ring)
+                        filed_rows = True
+                    else:
+                        ops.trsm_right(below, Lkk, dk)
         if not has_panel:
             return None
         # Row broadcast: skipped by a whole process row that has no tile rows below k.  The transposed
@@ -556,7 +587,7 @@ class DistributedGP:
                 piece = self.rowstg[: ntiles * nb * nb].view(ntiles * nb, nb)
             if self.rc:
                 h_row = self._bcast(piece.reshape(-1)[: R * nb], self._grank(p, qk), self.row_group, async_op=True)
-        out = dict(R=R, piece=piece, h_row=h_row, cnt_max=g.transposed_max(q, k), h_T=_Done())
+        out = dict(R=R, piece=piece, h_row=h_row, cnt_max=g.transposed_max(q, k), h_T=_Done(), filed_rows=filed_rows)
         if out["cnt_max"] > 0 and self.cc:
             t0, step, cnt = g.transposed_pick(p, q, k)
             cm = out["cnt_max"]
@@ -581,7 +612,8 @@ class DistributedGP:
         if R > 0:
             I1 = g.first_at_or_after(k + 1, p, P)
             h["h_row"].wait()
-            self.RB[g.lrow(I1): g.lrow(I1) + R, cols].copy_(h["piece"][:R])
+            if not h["filed_rows"]:          # (the panel solve of the owning process column wrote the ring itself)
+                self.RB[g.lrow(I1): g.lrow(I1) + R, cols].copy_(h["piece"][:R])
         if h["cnt_max"] == 0:
             return
         h["h_T"].wait()
@@ -663,9 +695,13 @@ class DistributedGP:
         W = self._winv.get(k)
         if W is None:
             hk = self.grid.tile_h(k)
-            W = self._winv[k] = self.ops.empty(hk, max(32, ((hk + 31) // 32) * 32))
+            store = self.__dict__.setdefault("_winv_store", {})     # buffers outlive a factorisation, contents do not
+            W = store.get(k)
+            if W is None or W.shape[0] != hk:
+                W = store[k] = self.ops.empty(hk, max(32, ((hk + 31) // 32) * 32))
             W[:, :hk].copy_(self.slabs[k][:hk, :hk])
             self.ops.trtri(W[:, :hk], self.dinv[k])
+            self._winv[k] = W
         return W
 
     def _solve_tile(self, trans, k, Rk, m, ncols=None):

@@ -151,6 +151,12 @@ int gpx_trmv(gpx_handle* h, int trans, int n, const double* W, int ldw, const do
  * the many-right-hand-side tile solves W B / W^T B of the multi-GPU path (regression.py:38,61). */
 int gpx_trmm(gpx_handle* h, int trans, int n, int m, const double* L, int ldl, const double* B, int ldb,
              double* Out, int ldo);
+/* Out (m x n) = X W^T for a lower-triangular n x n matrix W (only W[i][j], j <= i, is read), X m x n; Out must not
+ * alias X.  With W = L_kk^-1 (gpx_trtri of a diagonal tile) this is the panel solve A21 L11^-T inside
+ * scipy.linalg.cholesky (regression.py:36,49) as ONE triangular-aware MFMA product instead of the recursion of
+ * gpx_trsm_right over the tile's 128-blocks: the sharded Cholesky's panel step (distributed.py). */
+int gpx_trmm_right(gpx_handle* h, int m, int n, const double* W, int ldw, const double* X, int ldx, double* Out,
+                   int ldo);
 /* y(m) = A^T x for A n x m row-major (trans=1) or y(n) = A x (trans=0); fixed-order reduction.
  * regression.py:39 (mean = a . V), expectation_propagation.py:65,94,116. */
 int gpx_gemv(gpx_handle* h, int trans, int n, int m, const double* A, int lda, const double* x,

@@ -106,6 +106,9 @@ class NumpyOps:
         w = np.tril(W.numpy())
         Out.numpy()[...] = (w.T if trans else w) @ B.numpy()
 
+    def trmm_right(self, X, W, Out):
+        Out.numpy()[...] = X.numpy() @ np.tril(W.numpy()).T
+
     def logdet(self, L):
         return float(np.log(np.diagonal(L.numpy())).sum())
 

@@ -163,6 +163,21 @@ def test_gemm_colblocks_matches_numpy(rt, nb, ncols, K, M_extra):
     assert np.array_equal(got[untouched], store_h[untouched])
 
 
+@pytest.mark.parametrize("m,n", [(37, 128), (900, 512), (3000, 2048), (130, 300)])
+def test_trmm_right_matches_numpy(rt, m, n):
+    """Out = X W^T for a lower-triangular W whose strict upper triangle holds garbage (NaN): only j <= i is read.
+    With W = L_kk^-1 this is the panel solve A21 L11^-T of the sharded Cholesky as one product."""
+    rng = np.random.default_rng(m + n)
+    W = np.tril(rng.standard_normal((n, n)))
+    X = rng.standard_normal((m, n))
+    Wd = W.copy()
+    Wd[np.triu_indices(n, 1)] = np.nan
+    dW, dX = up(rt, Wd), up(rt, X)
+    Out = rt.matrix(m, n)
+    ok(rt.lib.gpx_trmm_right(rt.h, m, n, P(dW), dW.shape[1], P(dX), dX.shape[1], P(Out), Out.shape[1]))
+    assert relerr(down(rt, Out, m, n), X @ W.T) < 1e-13
+
+
 # ----------------------------------------------------------------------------- Gram
 @pytest.mark.parametrize("kind,d", [("rbf", 1), ("rbf", 3), ("ard", 2), ("ard", 8), ("ard", 5)])
 @pytest.mark.parametrize("n1,n2", [(1, 1), (15, 50), (129, 257), (300, 300), (700, 1537), (1100, 512)])   # the last two: 512-column strips, several row blocks of the packed lower grid

@@ -11,7 +11,8 @@ measured is what the rank itself has to do:
                 total and per panel; if host_ms >= gpu_ms the orchestration, not the GPU, bounds the rank
   recv_GB       bytes the rank receives over the factorisation (broadcast pieces it does not own, the other
                 members' parts of the transposed all-gather)
-  chain_ms      GPU time of the diagonal tiles' potrf + panel solves this rank runs (the factorisation's serial chain)
+  chain_ms      GPU time of the diagonal tiles' potrf, their inverses and the panel solves this rank runs (the
+                factorisation's serial chain)
 
     python tools/rank_share.py [n] [tile] [P] [Q]        (default 65536 512 2 4)
 """
@@ -119,7 +120,7 @@ def main():
         gp._file_panel = timed("file", gp._file_panel)
         gp._apply_many = timed("bulk", gp._apply_many)
         ops = gp.ops
-        for name in ("potrf_async", "trsm_right"):          # the chain pieces this rank runs, bracketed by events
+        for name in ("potrf_async", "trtri", "trmm_right", "trsm_right"):   # the chain pieces this rank runs, bracketed by events
             fn = getattr(ops, name)
 
             def w(*a, _fn=fn, **k):
@@ -151,7 +152,7 @@ def main():
         enq = 1e3 * sum(res["host"].values())
         T = gp.T
         print("rank %d (p=%d, q=%d): gpu %.1f ms | host enqueue %.1f ms = %.3f ms per panel (post %.1f, file %.1f, bulk updates %.1f) | "
-              "received %.2f GB in %d collective calls | chain (diagonal potrf + panel solves) %.1f ms | grouped update launches %d | "
+              "received %.2f GB in %d collective calls | chain (diagonal potrf + tile inverse + panel solves) %.1f ms | grouped update launches %d | "
               "resident matrix %.2f GB, panels %.2f GB"
               % (rank, p, q, res["gpu_ms"], enq, enq / T, 1e3 * res["host"]["post"], 1e3 * res["host"]["file"],
                  1e3 * res["host"]["bulk"], res["recv"] / 1e9, res["calls"], res["chain_ms"], res["grouped"],
