@@ -390,12 +390,14 @@ __global__ __launch_bounds__(256) void trmv_lower_n_kernel(int n, const double* 
 
 // y = W^T x: column sums per row chunk (as trsv_gemvt_partial_kernel), rows >= column only; chunks that lie
 // entirely above a strip's diagonal block write nothing and the final pass starts at the first one that does.
-__global__ __launch_bounds__(256) void trmv_lower_t_partial_kernel(int n, int npad, const double* W, long ldw,
+// (col0, pitch: the launch covers the columns [col0, col0 + pitch) and its partials are pitch wide -- one band of
+// columns at a time when n / rc chunks of n partials do not fit the scratch, n > 131008)
+__global__ __launch_bounds__(256) void trmv_lower_t_partial_kernel(int n, int col0, int pitch, const double* W, long ldw,
                                                                    const double* x, int rc, double* partials) {
   __shared__ double xs[XCHUNK];
   __shared__ v2d red[4][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int chunk = blockIdx.y, strip0 = blockIdx.x * NB;
+  const int chunk = blockIdx.y, strip0 = col0 + blockIdx.x * NB;
   const int col = strip0 + 2 * lane;
   const int i0 = chunk * rc, i1 = min(n, i0 + rc);
   if (i1 <= strip0) return;   // uniform
@@ -428,16 +430,16 @@ __global__ __launch_bounds__(256) void trmv_lower_t_partial_kernel(int n, int np
     s += red[1][lane];
     s += red[2][lane];
     s += red[3][lane];
-    *reinterpret_cast<v2d*>(partials + (size_t)chunk * npad + col) = s;
+    *reinterpret_cast<v2d*>(partials + (size_t)chunk * pitch + (col - col0)) = s;
   }
 }
 
-__global__ __launch_bounds__(256) void trmv_lower_t_final_kernel(int n, int npad, int nchunks, int rc,
+__global__ __launch_bounds__(256) void trmv_lower_t_final_kernel(int n, int col0, int pitch, int nchunks, int rc,
                                                                  const double* partials, double* y) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  const int j = col0 + blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || j >= col0 + pitch) return;
   double s = 0.0;
-  for (int c = ((j / NB) * NB) / rc; c < nchunks; ++c) s += partials[(size_t)c * npad + j];   // fixed order
+  for (int c = ((j / NB) * NB) / rc; c < nchunks; ++c) s += partials[(size_t)c * pitch + (j - col0)];   // fixed order
   y[j] = s;
 }
 
@@ -451,19 +453,31 @@ int gpx_trmv_lower_launch(hipStream_t s, int trans, int n, const double* W, long
     GPX_HIP(hipGetLastError());
     return 0;
   }
-  const int npad = (n + 1) & ~1;
+  const int npad = (n + NB - 1) / NB * NB;
   int rows = n <= 1024 ? 64 : NB;
   while ((size_t)((n + rows - 1) / rows) * npad > red_elems && rows < XCHUNK) rows *= 2;
   const int nchunks = (n + rows - 1) / rows;
-  if ((size_t)nchunks * npad > red_elems) {
+  // a chunk holds at most XCHUNK rows (its piece of x sits in LDS): beyond n ~ 131 000 the partials of all columns
+  // no longer fit the scratch at once, and the columns go band by band (the same kernels, the same sums)
+  size_t band = red_elems / nchunks / NB * NB;
+  if (band == 0) {
     gpx_set_error("trmv: reduction scratch too small (n = %d)", n);
     return GPX_ENOMEM;
   }
-  hipLaunchKernelGGL(trmv_lower_t_partial_kernel, dim3((n + NB - 1) / NB, nchunks), dim3(256), 0, s, n, npad, W, ldw,
-                     x, rows, red);
-  GPX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(trmv_lower_t_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, npad, nchunks, rows, red, y);
-  GPX_HIP(hipGetLastError());
+  static const long band_cap = [] {
+    const char* e = getenv("GPX_TRMV_BAND_COLS");   // development/test override: columns per band (multiple of 128)
+    return e ? atol(e) / NB * NB : 0L;
+  }();
+  if (band_cap > 0 && (size_t)band_cap < band) band = (size_t)band_cap;
+  if (band > (size_t)npad) band = npad;
+  for (int c0 = 0; c0 < n; c0 += (int)band) {
+    const int bw = (int)band < npad - c0 ? (int)band : npad - c0;
+    hipLaunchKernelGGL(trmv_lower_t_partial_kernel, dim3(bw / NB, nchunks), dim3(256), 0, s, n, c0, bw, W, ldw, x, rows,
+                       red);
+    GPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(trmv_lower_t_final_kernel, dim3((bw + 255) / 256), dim3(256), 0, s, n, c0, bw, nchunks, rows, red, y);
+    GPX_HIP(hipGetLastError());
+  }
   return 0;
 }
 

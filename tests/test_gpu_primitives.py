@@ -542,6 +542,41 @@ def test_trmv_lower_times_vector(rt, n):
         ok(rt.lib.gpx_trmv(rt.h, 0, n, P(dW), dW.shape[1], P(dx), P(dx)))
 
 
+def test_trmv_transposed_column_bands_give_the_same_product():
+    """y = W^T x keeps n / rows chunks of partial column sums in the handle's scratch; beyond n ~ 131 000 they no
+    longer fit at once and the columns go band by band (found at n = 131072: tools/big_n_grad.py).  Forced here with
+    bands of 256 columns (development override read at first use, hence the child process): bitwise the same sums."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import numpy as np, sys
+sys.path.insert(0, %r)
+from gaussian_process_amd import _lib
+from gaussian_process_amd.device import runtime, ptr
+rt = runtime(); rt.bind_stream()
+rng = np.random.default_rng(11)
+n = 1337
+W = np.tril(rng.standard_normal((n, n))); x = rng.standard_normal(n)
+dW, dx, dy = rt.upload_matrix(W), rt.upload_vector(x), rt.vector(n)
+_lib.check(rt.lib.gpx_trmv(rt.h, 1, n, ptr(dW), dW.shape[1], ptr(dx), ptr(dy)), "trmv")
+y = rt.download(dy[:n])
+print(repr(float(np.abs(y - W.T @ x).max() / np.abs(W.T @ x).max())), " ".join(repr(v) for v in y[:: 97]))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for band in ("", "256"):
+        env = dict(os.environ)
+        env.pop("GPX_TRMV_BAND_COLS", None)
+        if band:
+            env["GPX_TRMV_BAND_COLS"] = band
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = r.stdout.strip().splitlines()[-1].split()
+        assert float(line[0]) < 1e-13, line[0]
+        outs.append(line[1:])
+    assert outs[0] == outs[1]
+
+
 def test_grad_trace_row_bands_give_the_same_sums():
     """When the per-workgroup partials of a large n x d would not fit the reduction scratch the launch is
     split into row bands whose sums accumulate; forced here with one block row per band (development
