@@ -118,7 +118,8 @@ def test_bad_inputs_raise_like_reference():
         gp.fit(np.zeros(4), np.zeros(4))
 
 
-@pytest.mark.parametrize("n", [8192, 16384])      # 16384: BASELINE configs[2] at its exact size
+@pytest.mark.parametrize("n", [8192, 9001, 16384])      # 16384: BASELINE configs[2] at its exact size; 9001: ragged
+# blocks everywhere (recursion splits, the tail of the 1024-block solves, the last leaf)
 def test_large_size_properties(n):
     """Beyond the sizes the reference can run: size-independent properties.
     ||Ky alpha - y|| / ||y||, ||L L^T - Ky||_F / ||Ky||_F on sampled rows, LML against the oracle
