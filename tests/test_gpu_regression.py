@@ -387,3 +387,49 @@ def test_threads_and_streams_share_the_device_handle_safely():
         assert np.abs(g - ref).max() <= 1e-8 * np.abs(ref).max()
         mean_o, cov_o = O.gpr_predict("ard", X, y, Xs, 1.1, beta, noise)
         assert relerr(mean, mean_o) < TOL and relerr(cov, cov_o) < TOL
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_estimator_against_oracle_on_random_shapes(seed):
+    """Seeded random (n, d, m, kernel, noise) through the public estimator against the oracle: odd sizes on both sides
+    of every blocking (128-leaves, 256-row trsv leaves, 64/128-wide Gram strips), d from 1 to 12 (compiled and generic
+    dimension paths), single test points, both orders of LML / gradient / prediction."""
+    from gaussian_process_amd import ARD, RBF, GaussianProcessRegression
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([37, 129, 255, 257, 640, 1023, 1500, 2049, 2600, 3333]))
+    d = int(rng.choice([1, 2, 3, 5, 8, 12]))
+    m = int(rng.choice([1, 2, 63, 130, 301]))
+    kind = "ard" if seed % 2 == 0 else "rbf"
+    noise = float(rng.choice([0.02, 0.1, 1.0]))
+    sig_k = float(rng.uniform(0.5, 2.0))
+    X = rng.uniform(-2, 2, (n, d))
+    Xs = rng.uniform(-2, 2, (m, d))
+    y = np.sin(X @ rng.uniform(0.3, 1.0, d)) + 0.2 * rng.standard_normal(n)
+    beta = rng.uniform(0.2, 2.0, d) if kind == "ard" else float(rng.uniform(0.2, 2.0))
+    cov = ARD(sigma=sig_k, beta=beta) if kind == "ard" else RBF(sigma=sig_k, beta=beta)
+    gp = GaussianProcessRegression(cov=cov, sigma=noise)
+    gp.fit(X, y)
+    lml_o, _, L = O.gpr_lml(kind, X, y, sig_k, beta, noise)
+    g_o, alpha_o = O.gpr_grad(kind, X, y, sig_k, beta, noise, spd_inverse=True)
+    mean_o, cov_o = O.gpr_predict(kind, X, y, Xs, sig_k, beta, noise, L=L)
+    scale = max(np.abs(np.atleast_1d(v)).max() for v in g_o.values())
+
+    def check_grad():
+        g = gp.grad_log_marginal_likelihood()
+        for k in g_o:
+            assert np.abs(g[k] - np.atleast_1d(g_o[k])).max() <= 1e-8 * scale, (k, n, d, m, kind)
+
+    def check_predict():
+        mean, pc = gp.predict_with_variance(Xs)
+        assert mean.shape == (m,) and pc.shape == (m, m)
+        assert relerr(mean, mean_o) < TOL and relerr(pc, cov_o) < TOL, (n, d, m, kind)
+        assert relerr(gp.predict_with_variance(Xs, full_cov=False)[1], np.diagonal(cov_o)) < 1e-8
+
+    if seed % 3 == 0:            # gradient first: the prediction then runs from the inverse factor
+        check_grad()
+        check_predict()
+    else:
+        check_predict()
+        check_grad()
+    assert abs(gp.log_marginal_likelihood() - lml_o) <= TOL * abs(lml_o)
+    assert relerr(gp.alpha_(), alpha_o) < TOL
